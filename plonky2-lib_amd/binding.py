@@ -1,0 +1,258 @@
+"""ctypes binding of libglprover.so (C ABI: include/glp.h).
+
+Mirrors the plonky2 objects the reference touches on the prove() path:
+  Batch            <-> `PolynomialBatch`       (fri/oracle.rs)   from_values / from_coeffs / cap / prove / get
+  Context.fft/ifft <-> `PolynomialCoeffs::fft`, `PolynomialValues::ifft`
+Errors surface as GlpError carrying glp_last_error(), the analogue of the `anyhow::Error` that
+`data.prove(pw)` returns [REF src/ecdsa/gadgets/ecdsa.rs:349].
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+P = 0xFFFFFFFF00000001
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_SO = os.path.join(_HERE, "libglprover.so")
+_lib = None
+
+
+class GlpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("glp error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def exported_symbols():
+    """Function names declared in include/glp.h."""
+    hdr = open(os.path.join(_ROOT, "include", "glp.h")).read()
+    return re.findall(r"GLP_API [^;(]*?(glp_\w+)\(", hdr)
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise GlpError(-4, "libglprover.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(_SO)
+    vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+    L.glp_last_error.restype = C.c_char_p
+    L.glp_version.restype = C.c_char_p
+    L.glp_ctx_stream.restype = vp
+    L.glp_ctx_stream.argtypes = [vp]
+    L.glp_batch_num_digests.restype = sz
+    L.glp_batch_num_digests.argtypes = [vp]
+    sigs = {
+        "glp_ctx_create": [C.c_int, C.POINTER(vp)],
+        "glp_ctx_destroy": [vp],
+        "glp_ctx_synchronize": [vp],
+        "glp_ctx_set_profiling": [vp, C.c_int],
+        "glp_ctx_stage_reset": [vp],
+        "glp_ctx_stage_count": [vp],
+        "glp_ctx_stage_get": [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)],
+        "glp_poseidon_permute": [vp, vp, sz],
+        "glp_fft": [vp, vp, u32, u32],
+        "glp_ifft": [vp, vp, u32, u32],
+        "glp_lde": [vp, vp, u32, u32, u32, u64, vp],
+        "glp_batch_from_values": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_batch_from_values_device": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_batch_from_coeffs": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_batch_from_coeffs_device": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_batch_free": [vp],
+        "glp_batch_info": [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
+        "glp_batch_cap": [vp, vp],
+        "glp_batch_coeffs": [vp, u32, u32, vp],
+        "glp_batch_leaf": [vp, u64, vp],
+        "glp_batch_merkle_proof": [vp, u64, vp],
+        "glp_batch_digests": [vp, vp],
+    }
+    for name, argtypes in sigs.items():
+        getattr(L, name).argtypes = argtypes
+    L.glp_ctx_destroy.restype = None
+    L.glp_batch_free.restype = None
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GlpError(rc, load_library().glp_last_error().decode())
+
+
+def _a(x):
+    return np.ascontiguousarray(x, dtype=np.uint64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU + one HIP stream (glp_ctx)."""
+
+    def __init__(self, device=0):
+        L = load_library()
+        self._h = C.c_void_p()
+        _chk(L.glp_ctx_create(int(device), C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().glp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def synchronize(self):
+        _chk(load_library().glp_ctx_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return load_library().glp_ctx_stream(self._h)
+
+    # -- stage timers
+    def set_profiling(self, on=True):
+        _chk(load_library().glp_ctx_set_profiling(self._h, 1 if on else 0))
+
+    def stage_reset(self):
+        _chk(load_library().glp_ctx_stage_reset(self._h))
+
+    def stages(self):
+        L = load_library()
+        out = []
+        for i in range(L.glp_ctx_stage_count(self._h)):
+            name, ms, by = C.c_char_p(), C.c_float(), C.c_double()
+            _chk(L.glp_ctx_stage_get(self._h, i, C.byref(name), C.byref(ms), C.byref(by)))
+            out.append((name.value.decode(), ms.value, by.value))
+        return out
+
+    # -- primitives
+    def poseidon_permute(self, states):
+        s = _a(states).reshape(-1, 12).copy()
+        _chk(load_library().glp_poseidon_permute(self._h, _p(s), s.shape[0]))
+        return s
+
+    def fft(self, cols):
+        a = np.atleast_2d(_a(cols)).copy()
+        _chk(load_library().glp_fft(self._h, _p(a), a.shape[0], int(a.shape[1]).bit_length() - 1))
+        return a
+
+    def ifft(self, cols):
+        a = np.atleast_2d(_a(cols)).copy()
+        _chk(load_library().glp_ifft(self._h, _p(a), a.shape[0], int(a.shape[1]).bit_length() - 1))
+        return a
+
+    def lde(self, coeffs, rate_bits=3, shift=7):
+        a = np.atleast_2d(_a(coeffs))
+        out = np.empty((a.shape[0], a.shape[1] << rate_bits), np.uint64)
+        _chk(load_library().glp_lde(self._h, _p(a), a.shape[0], int(a.shape[1]).bit_length() - 1, rate_bits, shift, _p(out)))
+        return out
+
+    # -- PolynomialBatch
+    def batch_from_values(self, values, rate_bits=3, cap_height=4):
+        return Batch._make(self, "glp_batch_from_values", values, rate_bits, cap_height)
+
+    def batch_from_coeffs(self, coeffs, rate_bits=3, cap_height=4):
+        return Batch._make(self, "glp_batch_from_coeffs", coeffs, rate_bits, cap_height)
+
+    def batch_from_values_device(self, dev_ptr, ncols, log_n, rate_bits=3, cap_height=4):
+        return Batch._make_dev(self, "glp_batch_from_values_device", dev_ptr, ncols, log_n, rate_bits, cap_height)
+
+    def batch_from_coeffs_device(self, dev_ptr, ncols, log_n, rate_bits=3, cap_height=4):
+        return Batch._make_dev(self, "glp_batch_from_coeffs_device", dev_ptr, ncols, log_n, rate_bits, cap_height)
+
+
+class Batch:
+    """plonky2 `PolynomialBatch` resident on the GPU."""
+
+    def __init__(self, ctx, handle, ncols, log_n, rate_bits, cap_height):
+        self.ctx, self._h = ctx, handle
+        self.ncols, self.log_n, self.rate_bits, self.cap_height = ncols, log_n, rate_bits, cap_height
+
+    @classmethod
+    def _make(cls, ctx, fn, arr, rate_bits, cap_height):
+        a = _a(arr)
+        if a.ndim != 2:
+            raise GlpError(-1, "expected a [ncols][n] array")
+        ncols, n = a.shape
+        if n & (n - 1) or n == 0:
+            raise GlpError(-1, "n must be a power of two")
+        h = C.c_void_p()
+        _chk(getattr(load_library(), fn)(ctx._h, _p(a), ncols, n.bit_length() - 1, rate_bits, cap_height, C.byref(h)))
+        return cls(ctx, h, ncols, n.bit_length() - 1, rate_bits, cap_height)
+
+    @classmethod
+    def _make_dev(cls, ctx, fn, dev_ptr, ncols, log_n, rate_bits, cap_height):
+        h = C.c_void_p()
+        _chk(getattr(load_library(), fn)(ctx._h, C.c_void_p(dev_ptr), ncols, log_n, rate_bits, cap_height, C.byref(h)))
+        return cls(ctx, h, ncols, log_n, rate_bits, cap_height)
+
+    def free(self):
+        if self._h:
+            load_library().glp_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def num_leaves(self):
+        return 1 << (self.log_n + self.rate_bits)
+
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), np.uint64)
+        _chk(load_library().glp_batch_cap(self._h, _p(out)))
+        return out
+
+    def coeffs(self, col_begin=0, ncols=None):
+        ncols = self.ncols - col_begin if ncols is None else ncols
+        out = np.empty((ncols, 1 << self.log_n), np.uint64)
+        _chk(load_library().glp_batch_coeffs(self._h, col_begin, ncols, _p(out)))
+        return out
+
+    def leaf(self, index):
+        out = np.empty(self.ncols, np.uint64)
+        _chk(load_library().glp_batch_leaf(self._h, int(index), _p(out)))
+        return out
+
+    def prove(self, index):
+        depth = self.log_n + self.rate_bits - self.cap_height
+        out = np.empty((depth, 4), np.uint64)
+        _chk(load_library().glp_batch_merkle_proof(self._h, int(index), _p(out)))
+        return out
+
+    def digests(self):
+        n = load_library().glp_batch_num_digests(self._h)
+        out = np.empty((n, 4), np.uint64)
+        _chk(load_library().glp_batch_digests(self._h, _p(out)))
+        return out

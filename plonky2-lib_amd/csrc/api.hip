@@ -1,0 +1,416 @@
+// api.hip -- the extern "C" boundary of libglprover.so (declared in include/glp.h): context,
+// device-memory pool, stage timers, primitive entry points and PolynomialBatch.
+#include <stdarg.h>
+#include <string.h>
+#include "batch.h"
+#include "common.h"
+#include "merkle.h"
+#include "ntt.h"
+
+namespace glp {
+thread_local std::string g_last_error;
+int set_error(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+}  // namespace glp
+using namespace glp;
+
+// ------------------------------------------------------------------------------------------ ctx
+int glp_ctx::alloc(void **p, size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto it = pool.find(bytes);
+    if (it != pool.end()) {
+        *p = it->second;
+        pool.erase(it);
+        pool_bytes -= bytes;
+        live[*p] = bytes;
+        return GLP_OK;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        trim();  // drop cached blocks of other sizes and retry once
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) return set_error(GLP_ERR_HIP, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    live[*p] = bytes;
+    return GLP_OK;
+}
+void glp_ctx::release(void *p) {
+    if (!p) return;
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    pool.insert({it->second, p});
+    pool_bytes += it->second;
+    live.erase(it);
+}
+void glp_ctx::trim() {
+    (void)hipStreamSynchronize(stream);
+    for (auto &kv : pool) (void)hipFree(kv.second);
+    pool.clear();
+    pool_bytes = 0;
+}
+int glp_ctx::stage_begin(const char *name, double bytes) {
+    if (!profiling) return GLP_OK;
+    Stage s;
+    s.name = name; s.bytes = bytes;
+    if (hipEventCreate(&s.beg) != hipSuccess || hipEventCreate(&s.end) != hipSuccess) return GLP_ERR_HIP;
+    (void)hipEventRecord(s.beg, stream);
+    stages.push_back(s);
+    return GLP_OK;
+}
+int glp_ctx::stage_end() {
+    if (!profiling || stages.empty()) return GLP_OK;
+    (void)hipEventRecord(stages.back().end, stream);
+    return GLP_OK;
+}
+
+extern "C" {
+
+const char *glp_last_error(void) { return g_last_error.c_str(); }
+const char *glp_version(void) { return "glprover 0.1 (gfx950)"; }
+
+int glp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int glp_ctx_create(int device_id, glp_ctx **out) {
+    GLP_REQUIRE(out != nullptr, "glp_ctx_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return set_error(GLP_ERR_NOGPU, "no HIP device visible (%s); libglprover has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    GLP_REQUIRE(device_id >= 0 && device_id < n, "device_id %d out of range (0..%d)", device_id, n - 1);
+    GLP_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    GLP_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(GLP_ERR_NOGPU, "device %d is %s; this library carries gfx950 code objects only", device_id,
+                         prop.gcnArchName);
+    std::unique_ptr<glp_ctx> c(new glp_ctx());
+    c->device = device_id;
+    c->num_cus = prop.multiProcessorCount;
+    GLP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c.release();
+    return GLP_OK;
+}
+
+void glp_ctx_destroy(glp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    glp_ctx_stage_reset(c);
+    free_plans(c);
+    c->trim();
+    for (auto &kv : c->live) (void)hipFree(kv.first);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int glp_ctx_synchronize(glp_ctx *c) {
+    GLP_REQUIRE(c, "null ctx");
+    GLP_TRY(bind(c));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+void *glp_ctx_stream(glp_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int glp_ctx_set_profiling(glp_ctx *c, int on) {
+    GLP_REQUIRE(c, "null ctx");
+    c->profiling = on != 0;
+    return GLP_OK;
+}
+int glp_ctx_stage_reset(glp_ctx *c) {
+    GLP_REQUIRE(c, "null ctx");
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->stages) { (void)hipEventDestroy(s.beg); (void)hipEventDestroy(s.end); }
+    c->stages.clear();
+    return GLP_OK;
+}
+int glp_ctx_stage_count(glp_ctx *c) { return c ? (int)c->stages.size() : 0; }
+int glp_ctx_stage_get(glp_ctx *c, int index, const char **name, float *ms, double *bytes) {
+    GLP_REQUIRE(c && index >= 0 && index < (int)c->stages.size(), "stage index out of range");
+    Stage &s = c->stages[index];
+    GLP_HIP(hipEventSynchronize(s.end));
+    float t = 0;
+    GLP_HIP(hipEventElapsedTime(&t, s.beg, s.end));
+    if (name) *name = s.name.c_str();
+    if (ms) *ms = t;
+    if (bytes) *bytes = s.bytes;
+    return GLP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ primitives
+struct Scratch {  // RAII for pool blocks inside one API call
+    glp_ctx *c;
+    std::vector<void *> ptrs;
+    explicit Scratch(glp_ctx *ctx) : c(ctx) {}
+    ~Scratch() { (void)hipStreamSynchronize(c->stream); for (void *p : ptrs) c->release(p); }
+    int get(u64 **p, size_t elems) {
+        void *v = nullptr;
+        int rc = c->alloc(&v, elems * sizeof(u64));
+        if (rc == GLP_OK) { ptrs.push_back(v); *p = (u64 *)v; }
+        return rc;
+    }
+};
+
+int glp_poseidon_permute(glp_ctx *c, uint64_t *states, size_t count) {
+    GLP_REQUIRE(c && (states || !count), "null argument");
+    GLP_TRY(bind(c));
+    if (!count) return GLP_OK;
+    Scratch s(c);
+    u64 *d;
+    GLP_TRY(s.get(&d, count * 12));
+    GLP_HIP(hipMemcpyAsync(d, states, count * 96, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(poseidon_permute_states(c, d, count));
+    GLP_HIP(hipMemcpyAsync(states, d, count * 96, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int glp_fft(glp_ctx *c, uint64_t *cols, uint32_t ncols, uint32_t log_n) {
+    GLP_REQUIRE(c && (cols || !ncols), "null argument");
+    GLP_TRY(bind(c));
+    if (!ncols) return GLP_OK;
+    if (log_n > (uint32_t)NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%u > %d", log_n, NTT_MAX_LG);
+    const size_t tot = (size_t)ncols << log_n;
+    Scratch s(c);
+    u64 *a, *b;
+    GLP_TRY(s.get(&a, tot));
+    GLP_TRY(s.get(&b, tot));
+    GLP_HIP(hipMemcpyAsync(a, cols, tot * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(bitrev_copy(c, a, b, ncols, (int)log_n));
+    GLP_TRY(ntt_coeffs_to_values(c, b, a, ncols, (int)log_n));
+    GLP_HIP(hipMemcpyAsync(cols, a, tot * 8, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int glp_ifft(glp_ctx *c, uint64_t *cols, uint32_t ncols, uint32_t log_n) {
+    GLP_REQUIRE(c && (cols || !ncols), "null argument");
+    GLP_TRY(bind(c));
+    if (!ncols) return GLP_OK;
+    if (log_n > (uint32_t)NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%u > %d", log_n, NTT_MAX_LG);
+    const size_t tot = (size_t)ncols << log_n;
+    Scratch s(c);
+    u64 *a, *b;
+    GLP_TRY(s.get(&a, tot));
+    GLP_TRY(s.get(&b, tot));
+    GLP_HIP(hipMemcpyAsync(a, cols, tot * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(intt_values_to_coeffs(c, a, b, ncols, (int)log_n));
+    GLP_TRY(bitrev_copy(c, b, a, ncols, (int)log_n));
+    GLP_HIP(hipMemcpyAsync(cols, a, tot * 8, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int glp_lde(glp_ctx *c, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits, uint64_t shift,
+            uint64_t *out) {
+    GLP_REQUIRE(c && ((coeffs && out) || !ncols), "null argument");
+    GLP_REQUIRE(shift != 0 && shift < glf::P, "shift must be a nonzero canonical field element");
+    GLP_TRY(bind(c));
+    if (!ncols) return GLP_OK;
+    if (log_n > (uint32_t)NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%u > %d", log_n, NTT_MAX_LG);
+    const size_t tot = (size_t)ncols << log_n, TOT = tot << rate_bits;
+    Scratch s(c);
+    u64 *a, *b, *l, *o;
+    GLP_TRY(s.get(&a, tot));
+    GLP_TRY(s.get(&b, tot));
+    GLP_TRY(s.get(&l, TOT));
+    GLP_TRY(s.get(&o, TOT));
+    GLP_HIP(hipMemcpyAsync(a, coeffs, tot * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(bitrev_copy(c, a, b, ncols, (int)log_n));
+    GLP_TRY(lde_coeffs(c, b, l, ncols, (int)log_n, (int)rate_bits, shift));
+    GLP_TRY(lde_to_natural(c, l, o, ncols, (int)log_n, (int)rate_bits));
+    GLP_HIP(hipMemcpyAsync(out, o, TOT * 8, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PolynomialBatch
+}  // extern "C"
+
+namespace glp {
+
+void batch_destroy(glp_batch *b) {
+    if (!b) return;
+    glp_ctx *c = b->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(b->coeffs);
+    c->release(b->lde);
+    c->release(b->digests);
+    delete b;
+}
+
+// dev_in: values (natural) if from_values, else coefficients in natural order.
+int batch_build(glp_ctx *c, const u64 *dev_in, bool from_values, u32 ncols, int lg, int rate_bits, int cap_height,
+                glp_batch **out) {
+    GLP_REQUIRE(out, "out is null");
+    *out = nullptr;
+    GLP_REQUIRE(ncols > 0, "ncols must be positive");
+    if (lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d > %d (three-pass NTT not built yet)", lg, NTT_MAX_LG);
+    GLP_REQUIRE(rate_bits >= 0 && rate_bits <= 4, "rate_bits=%d outside 0..4", rate_bits);
+    GLP_REQUIRE(cap_height >= 0 && cap_height <= lg + rate_bits, "cap_height=%d should be at most log2(leaves)=%d", cap_height,
+                lg + rate_bits);
+    const size_t n = (size_t)1 << lg, N = n << rate_bits;
+    std::unique_ptr<glp_batch, void (*)(glp_batch *)> b(new glp_batch(), batch_destroy);
+    b->ctx = c; b->ncols = ncols; b->lg = lg; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->ndigests = merkle_num_digests(N, cap_height);
+    GLP_TRY(c->alloc((void **)&b->coeffs, (size_t)ncols * n * 8));
+    GLP_TRY(c->alloc((void **)&b->lde, (size_t)ncols * N * 8));
+    GLP_TRY(c->alloc((void **)&b->digests, b->ndigests * 32));
+    if (from_values) {
+        StageScope st(c, "intt", 16.0 * n * ncols);
+        GLP_TRY(intt_values_to_coeffs(c, dev_in, b->coeffs, ncols, lg));
+    } else {
+        StageScope st(c, "bitrev_coeffs", 16.0 * n * ncols);
+        GLP_TRY(bitrev_copy(c, dev_in, b->coeffs, ncols, lg));
+    }
+    {
+        StageScope st(c, "lde", (8.0 * n + 8.0 * N) * ncols);
+        GLP_TRY(lde_coeffs(c, b->coeffs, b->lde, ncols, lg, rate_bits, glf::GEN));
+    }
+    GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests));
+    *out = b.release();
+    return GLP_OK;
+}
+
+static int batch_from_host(glp_ctx *c, const u64 *host, bool from_values, u32 ncols, u32 log_n, u32 rate_bits, u32 cap_height,
+                           glp_batch **out) {
+    GLP_REQUIRE(c && host && out, "null argument");
+    GLP_TRY(bind(c));
+    if (log_n > (u32)NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%u > %d", log_n, NTT_MAX_LG);
+    const size_t tot = (size_t)ncols << log_n;
+    void *d = nullptr;
+    GLP_TRY(c->alloc(&d, tot * 8));
+    int rc = GLP_OK;
+    hipError_t e = hipMemcpyAsync(d, host, tot * 8, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+    if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, from_values, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(d);
+    return rc;
+}
+
+}  // namespace glp
+
+extern "C" {
+
+int glp_batch_from_values(glp_ctx *c, const uint64_t *values, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
+                          uint32_t cap_height, glp_batch **out) {
+    return batch_from_host(c, values, true, ncols, log_n, rate_bits, cap_height, out);
+}
+int glp_batch_from_coeffs(glp_ctx *c, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
+                          uint32_t cap_height, glp_batch **out) {
+    return batch_from_host(c, coeffs, false, ncols, log_n, rate_bits, cap_height, out);
+}
+int glp_batch_from_values_device(glp_ctx *c, const uint64_t *dev_values, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                 uint32_t cap_height, glp_batch **out) {
+    GLP_REQUIRE(c && dev_values && out, "null argument");
+    GLP_TRY(bind(c));
+    return batch_build(c, dev_values, true, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+}
+int glp_batch_from_coeffs_device(glp_ctx *c, const uint64_t *dev_coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                 uint32_t cap_height, glp_batch **out) {
+    GLP_REQUIRE(c && dev_coeffs && out, "null argument");
+    GLP_TRY(bind(c));
+    return batch_build(c, dev_coeffs, false, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+}
+void glp_batch_free(glp_batch *b) { batch_destroy(b); }
+
+int glp_batch_info(const glp_batch *b, uint32_t *ncols, uint32_t *log_n, uint32_t *rate_bits, uint32_t *cap_height) {
+    GLP_REQUIRE(b, "null batch");
+    if (ncols) *ncols = b->ncols;
+    if (log_n) *log_n = (u32)b->lg;
+    if (rate_bits) *rate_bits = (u32)b->rate_bits;
+    if (cap_height) *cap_height = (u32)b->cap_height;
+    return GLP_OK;
+}
+
+int glp_batch_cap(const glp_batch *b, uint64_t *cap_out) {
+    GLP_REQUIRE(b && cap_out, "null argument");
+    glp_ctx *c = b->ctx;
+    GLP_TRY(bind(c));
+    const size_t N = (size_t)1 << (b->lg + b->rate_bits);
+    const size_t off = merkle_cap_offset(N, b->cap_height);
+    GLP_HIP(hipMemcpyAsync(cap_out, b->digests + 4 * off, ((size_t)32) << b->cap_height, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int glp_batch_coeffs(const glp_batch *b, uint32_t col_begin, uint32_t ncols, uint64_t *out) {
+    GLP_REQUIRE(b && (out || !ncols), "null argument");
+    GLP_REQUIRE((u64)col_begin + ncols <= b->ncols, "column range out of bounds");
+    if (!ncols) return GLP_OK;
+    glp_ctx *c = b->ctx;
+    GLP_TRY(bind(c));
+    const size_t n = (size_t)1 << b->lg;
+    Scratch s(c);
+    u64 *t;
+    GLP_TRY(s.get(&t, (size_t)ncols * n));
+    GLP_TRY(bitrev_copy(c, b->coeffs + (size_t)col_begin * n, t, ncols, b->lg));
+    GLP_HIP(hipMemcpyAsync(out, t, (size_t)ncols * n * 8, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int glp_batch_leaf(const glp_batch *b, uint64_t leaf_index, uint64_t *out) {
+    GLP_REQUIRE(b && out, "null argument");
+    const size_t N = (size_t)1 << (b->lg + b->rate_bits);
+    GLP_REQUIRE(leaf_index < N, "leaf_index out of range");
+    glp_ctx *c = b->ctx;
+    GLP_TRY(bind(c));
+    Scratch s(c);
+    u64 *idx, *t;
+    GLP_TRY(s.get(&idx, 1));
+    GLP_TRY(s.get(&t, b->ncols));
+    GLP_HIP(hipMemcpyAsync(idx, &leaf_index, 8, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(merkle_gather_lde_rows(c, b->lde, b->ncols, b->lg, b->rate_bits, idx, 1, t));
+    GLP_HIP(hipMemcpyAsync(out, t, (size_t)b->ncols * 8, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int glp_batch_merkle_proof(const glp_batch *b, uint64_t leaf_index, uint64_t *siblings_out) {
+    GLP_REQUIRE(b, "null argument");
+    const size_t N = (size_t)1 << (b->lg + b->rate_bits);
+    GLP_REQUIRE(leaf_index < N, "leaf_index out of range");
+    const int depth = b->lg + b->rate_bits - b->cap_height;
+    if (depth == 0) return GLP_OK;
+    GLP_REQUIRE(siblings_out, "null argument");
+    glp_ctx *c = b->ctx;
+    GLP_TRY(bind(c));
+    Scratch s(c);
+    u64 *idx, *t;
+    GLP_TRY(s.get(&idx, 1));
+    GLP_TRY(s.get(&t, (size_t)depth * 4));
+    GLP_HIP(hipMemcpyAsync(idx, &leaf_index, 8, hipMemcpyHostToDevice, c->stream));
+    GLP_TRY(merkle_gather_paths(c, b->digests, N, b->cap_height, idx, 1, t));
+    GLP_HIP(hipMemcpyAsync(siblings_out, t, (size_t)depth * 32, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+size_t glp_batch_num_digests(const glp_batch *b) { return b ? b->ndigests : 0; }
+
+int glp_batch_digests(const glp_batch *b, uint64_t *out) {
+    GLP_REQUIRE(b && out, "null argument");
+    glp_ctx *c = b->ctx;
+    GLP_TRY(bind(c));
+    GLP_HIP(hipMemcpyAsync(out, b->digests, b->ndigests * 32, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+}  // extern "C"

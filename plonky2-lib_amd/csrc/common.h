@@ -1,0 +1,77 @@
+// common.h -- context, device-memory pool, error plumbing and stage timers shared by the
+// translation units of libglprover.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/glp.h"
+#include "glf.h"
+
+namespace glp {
+
+extern thread_local std::string g_last_error;
+int set_error(int code, const char *fmt, ...);
+
+#define GLP_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return glp::set_error(GLP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                  __FILE__, __LINE__);                                         \
+    } while (0)
+#define GLP_TRY(expr)              \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != GLP_OK) return _rc; \
+    } while (0)
+#define GLP_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) return glp::set_error(GLP_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+struct NttPlan;
+struct LdePlan;
+
+struct Stage {
+    std::string name;
+    hipEvent_t beg, end;
+    double bytes;
+};
+
+}  // namespace glp
+
+struct glp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    // size-keyed free lists: commit buffers are GB-sized and recur with identical sizes every proof
+    std::multimap<size_t, void *> pool;
+    std::map<void *, size_t> live;
+    size_t pool_bytes = 0;
+    std::map<int, glp::NttPlan *> ntt_plans;                       // key: log_n
+    std::map<std::pair<std::pair<int, int>, u64>, glp::LdePlan *> lde_plans;  // key: ((log_n, rate_bits), shift)
+    bool profiling = false;
+    std::vector<glp::Stage> stages;
+
+    int alloc(void **p, size_t bytes);
+    void release(void *p);
+    void trim();
+    int stage_begin(const char *name, double bytes);
+    int stage_end();
+};
+
+namespace glp {
+struct StageScope {
+    glp_ctx *c;
+    StageScope(glp_ctx *ctx, const char *name, double bytes) : c(ctx) { c->stage_begin(name, bytes); }
+    ~StageScope() { c->stage_end(); }
+};
+inline int bind(glp_ctx *c) {
+    hipError_t e = hipSetDevice(c->device);
+    return e == hipSuccess ? GLP_OK : set_error(GLP_ERR_HIP, "hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+}
+}  // namespace glp

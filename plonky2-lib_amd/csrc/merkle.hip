@@ -1,0 +1,206 @@
+// merkle.hip -- Poseidon sponge leaf hashing and 2-to-1 tree levels for gfx950.
+//
+// Replaces plonky2 `hash/merkle_tree.rs` (MerkleTree::new / prove / get) with
+// `PoseidonHash::{hash_or_noop, two_to_one}` (`hash/poseidon.rs`, `hashing.rs`) as called from
+// `PolynomialBatch::from_coeffs` and `fri_committed_trees` on the prove() path
+// [REF src/ecdsa/gadgets/ecdsa.rs:349].  The same two primitives are what the reference calls
+// natively at [REF src/smt/goldilocks_poseidon/mod.rs:165,170-180].
+//
+// One sponge state per lane.  The LDE matrix is column-major with rows in coset-major order, so
+// lane `pos` reads lde[c][pos] for every column c: one fully coalesced 512-byte request per
+// column per wave.  No transpose pass exists; the bit-reversed leaf order of plonky2 is produced
+// by scattering the 32-byte digest to slot bitrev(pos).
+#include "merkle.h"
+#include "poseidon.h"
+
+namespace glp {
+using namespace glf;
+
+size_t merkle_num_digests(size_t nleaves, int cap_height) {
+    size_t t = 0, w = nleaves, cap = (size_t)1 << cap_height;
+    for (;;) { t += w; if (w <= cap) break; w >>= 1; }
+    return t;
+}
+size_t merkle_cap_offset(size_t nleaves, int cap_height) {
+    return merkle_num_digests(nleaves, cap_height) - ((size_t)1 << cap_height);
+}
+
+__device__ __forceinline__ void store_digest(u64 *dst, const u64 s[12]) {
+    ulonglong2 a, b;
+    a.x = s[0]; a.y = s[1]; b.x = s[2]; b.y = s[3];
+    reinterpret_cast<ulonglong2 *>(dst)[0] = a;
+    reinterpret_cast<ulonglong2 *>(dst)[1] = b;
+}
+
+// hash_or_noop of one LDE row per lane.  grid.x * 256 >= N
+__global__ __launch_bounds__(256) void k_leaf_hash_lde(const u64 *__restrict__ lde, u64 *__restrict__ digests,
+                                                       u32 ncols, int lg, int rate_bits) {
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= N) return;
+    const u32 r = (u32)(pos >> lg), q = (u32)(pos & (((size_t)1 << lg) - 1));
+    const size_t leaf = ((size_t)bitrev32(r, rate_bits) << lg) | bitrev32(q, lg);
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const u64 *p = lde + pos;
+    if (ncols <= 4) {
+        for (u32 c = 0; c < ncols; c++) s[c] = p[(size_t)c * N];
+    } else {
+        u32 c = 0;
+        for (; c + 8 <= ncols; c += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = p[(size_t)(c + i) * N];
+            pos::permute(s);
+        }
+        if (c < ncols) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c + i < ncols) s[i] = p[(size_t)(c + i) * N];
+            pos::permute(s);
+        }
+    }
+    store_digest(digests + 4 * leaf, s);
+}
+
+// hash_or_noop of row-major leaves [nleaves][leaf_len]
+__global__ __launch_bounds__(256) void k_leaf_hash_rows(const u64 *__restrict__ rows, u64 *__restrict__ digests,
+                                                        size_t nleaves, u32 leaf_len) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= nleaves) return;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const u64 *p = rows + j * leaf_len;
+    if (leaf_len <= 4) {
+        for (u32 c = 0; c < leaf_len; c++) s[c] = p[c];
+    } else {
+        u32 c = 0;
+        for (; c + 8 <= leaf_len; c += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = p[c + i];
+            pos::permute(s);
+        }
+        if (c < leaf_len) {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (c + i < leaf_len) s[i] = p[c + i];
+            pos::permute(s);
+        }
+    }
+    store_digest(digests + 4 * j, s);
+}
+
+// one tree level: out[i] = two_to_one(in[2i], in[2i+1])
+__global__ __launch_bounds__(256) void k_merkle_level(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(in + 8 * i);
+    ulonglong2 a = src[0], b = src[1], c2 = src[2], d = src[3];
+    u64 s[12] = {a.x, a.y, b.x, b.y, c2.x, c2.y, d.x, d.y, 0, 0, 0, 0};
+    pos::permute(s);
+    store_digest(out + 4 * i, s);
+}
+
+__global__ void k_permute_states(u64 *states, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 s[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = states[12 * i + k];
+    pos::permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
+}
+
+static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height) {
+    size_t w = nleaves, cap = (size_t)1 << cap_height;
+    u64 *lvl = dev_digests;
+    while (w > cap) {
+        u64 *nxt = lvl + 4 * w;
+        size_t m = w >> 1;
+        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, lvl, nxt, m);
+        GLP_HIP(hipGetLastError());
+        lvl = nxt; w = m;
+    }
+    return GLP_OK;
+}
+
+int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, int cap_height, u64 *dev_digests) {
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    if (cap_height < 0 || ((size_t)1 << cap_height) > N)
+        return set_error(GLP_ERR_ARG, "cap_height=%d should be at most log2(leaves)=%d", cap_height, lg + rate_bits);
+    {
+        StageScope st(c, "merkle_leaves", (double)N * (8.0 * ncols + 32.0));
+        hipLaunchKernelGGL(k_leaf_hash_lde, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, dev_lde, dev_digests,
+                           ncols, lg, rate_bits);
+        GLP_HIP(hipGetLastError());
+    }
+    StageScope st(c, "merkle_levels", (double)N * 32.0 * 1.5);
+    return build_levels(c, dev_digests, N, cap_height);
+}
+
+int merkle_from_rows(glp_ctx *c, const u64 *dev_rows, size_t nleaves, u32 leaf_len, int cap_height, u64 *dev_digests) {
+    if (cap_height < 0 || ((size_t)1 << cap_height) > nleaves)
+        return set_error(GLP_ERR_ARG, "cap_height=%d should be at most log2(leaves)", cap_height);
+    hipLaunchKernelGGL(k_leaf_hash_rows, dim3((unsigned)((nleaves + 255) / 256)), dim3(256), 0, c->stream, dev_rows,
+                       dev_digests, nleaves, leaf_len);
+    GLP_HIP(hipGetLastError());
+    return build_levels(c, dev_digests, nleaves, cap_height);
+}
+
+__global__ void k_gather_lde_rows(const u64 *__restrict__ lde, u32 ncols, int lg, int rate_bits,
+                                  const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out) {
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)count * ncols) return;
+    const u32 k = (u32)(t / ncols), col = (u32)(t % ncols);
+    const u64 j = leaf_idx[k];
+    // leaf j <-> point index i = bitrev_N(j) = q*R + r  <-> slot (r, q)
+    const u32 rtop = (u32)(j >> lg), jl = (u32)(j & (((u64)1 << lg) - 1));
+    const size_t pos = ((size_t)bitrev32(rtop, rate_bits) << lg) | bitrev32(jl, lg);
+    out[t] = lde[(size_t)col * N + pos];
+}
+
+__global__ void k_gather_paths(const u64 *__restrict__ digests, size_t nleaves, int depth,
+                               const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)count * depth * 4) return;
+    const u32 e = (u32)(t & 3);
+    const u32 lvl = (u32)((t >> 2) % depth), k = (u32)((t >> 2) / depth);
+    size_t off = 0, w = nleaves;
+    for (u32 l = 0; l < lvl; l++) { off += w; w >>= 1; }
+    const size_t idx = (leaf_idx[k] >> lvl) ^ 1;
+    out[t] = digests[4 * (off + idx) + e];
+}
+
+int merkle_gather_lde_rows(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, const u64 *dev_leaf_idx,
+                           u32 count, u64 *dev_out) {
+    const size_t total = (size_t)count * ncols;
+    if (!total) return GLP_OK;
+    hipLaunchKernelGGL(k_gather_lde_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dev_lde, ncols, lg,
+                       rate_bits, dev_leaf_idx, count, dev_out);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+int merkle_gather_paths(glp_ctx *c, const u64 *dev_digests, size_t nleaves, int cap_height, const u64 *dev_leaf_idx,
+                        u32 count, u64 *dev_out) {
+    int depth = 0;
+    for (size_t w = nleaves; w > ((size_t)1 << cap_height); w >>= 1) depth++;
+    const size_t total = (size_t)count * depth * 4;
+    if (!total) return GLP_OK;
+    hipLaunchKernelGGL(k_gather_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dev_digests, nleaves,
+                       depth, dev_leaf_idx, count, dev_out);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+int poseidon_permute_states(glp_ctx *c, u64 *dev_states, size_t count) {
+    if (!count) return GLP_OK;
+    hipLaunchKernelGGL(k_permute_states, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, dev_states, count);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+}  // namespace glp

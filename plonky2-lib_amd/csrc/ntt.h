@@ -1,0 +1,52 @@
+// ntt.h -- batched Goldilocks NTT / iNTT / low-degree extension over column-major device arrays.
+//
+// Device layouts (chosen for coalescing on gfx950, not plonky2's host layouts):
+//   trace values   [ncols][n]            natural order (row i = w^i)
+//   coefficients   [ncols][n]            BIT-REVERSED order: slot p holds the coefficient of X^bitrev(p)
+//   LDE values     [ncols][R][n]         "coset-major": slot (r, q) holds p(shift * W^(q*R + r)),
+//                                        R = 2^rate_bits, W = primitive_root_of_unity(log_n + rate_bits)
+// An inverse transform is decimation-in-frequency (natural -> bit-reversed), a forward one
+// decimation-in-time (bit-reversed -> natural), so no permutation pass ever touches HBM.
+// A size-n transform is two LDS-staged passes, n = A * B: a strided pass over A rows (tile A x 16
+// columns, 128-byte row segments) and a contiguous pass over B <= 4096 elements.
+#pragma once
+#include "common.h"
+
+namespace glp {
+
+constexpr int NTT_MAX_LG = 20;      // two-pass limit: B <= 2^12 (contiguous), A <= 2^8 (strided)
+constexpr int NTT_LGB_MAX = 12;
+constexpr int NTT_LGA_MAX = 8;
+constexpr int NTT_STRIDED_W = 16;   // columns per strided tile (16 x 8 B = one 128-B line per row)
+
+struct NttPlan {
+    int lg, lgA, lgB;
+    u64 *tw_B = nullptr, *itw_B = nullptr;   // w_B^j / w_B^-j, j < B/2
+    u64 *tw_A = nullptr, *itw_A = nullptr;   // w_A^j / w_A^-j, j < A/2
+    u64 w_n, w_n_inv, n_inv;
+};
+
+struct LdePlan {
+    const NttPlan *ntt;
+    int rate_bits;
+    u64 shift;
+    u64 *pre = nullptr;      // [R][B]: (s_r^A)^bitrev_B(pl),  s_r = shift * W^r
+    u64 *s_r = nullptr;      // [R]
+};
+
+int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out);
+int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out);
+void free_plans(glp_ctx *c);
+
+// values [ncols][n] natural  ->  coefficients [ncols][n] bit-reversed   (PolynomialValues::ifft)
+int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg);
+// coefficients bit-reversed -> values natural (PolynomialCoeffs::fft), in place allowed (out == in)
+int ntt_coeffs_to_values(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_values, u32 ncols, int lg);
+// coefficients [ncols][n] bit-reversed -> LDE [ncols][R][n] coset-major   (lde + coset_fft(shift))
+int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift);
+// out[c][bitrev(p)] = in[c][p]  (layout conversion for accessors; not on the prove path)
+int bitrev_copy(glp_ctx *c, const u64 *dev_in, u64 *dev_out, u32 ncols, int lg);
+// coset-major [ncols][R][n] -> natural [ncols][N]  (accessor only)
+int lde_to_natural(glp_ctx *c, const u64 *dev_lde, u64 *dev_out, u32 ncols, int lg, int rate_bits);
+
+}  // namespace glp

@@ -1,0 +1,384 @@
+// ntt.hip -- LDS-staged two-pass Goldilocks NTT kernels for gfx950 (see ntt.h for layouts).
+//
+// Replaces plonky2 `field/src/fft.rs` (fft_dispatch / ifft_with_options) and
+// `polynomial/mod.rs` (lde, coset_fft_with_options) as called from
+// `PolynomialBatch::from_values / from_coeffs` on the prove() path
+// [REF src/ecdsa/gadgets/ecdsa.rs:349].  No MFMA: 64-bit modular integer butterflies.
+#include "ntt.h"
+
+namespace glp {
+using namespace glf;
+
+// ------------------------------------------------------------------------------------------
+// host-side plan construction (tables are a few KB; built once per (log_n, rate_bits, shift))
+// ------------------------------------------------------------------------------------------
+static int upload(glp_ctx *c, const std::vector<u64> &h, u64 **dev) {
+    size_t bytes = (h.size() ? h.size() : 1) * sizeof(u64);
+    GLP_HIP(hipMalloc((void **)dev, bytes));
+    if (h.size()) GLP_HIP(hipMemcpyAsync(*dev, h.data(), h.size() * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
+int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out) {
+    if (lg < 0 || lg > NTT_MAX_LG)
+        return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d outside the supported range 0..%d", lg, NTT_MAX_LG);
+    auto it = c->ntt_plans.find(lg);
+    if (it != c->ntt_plans.end()) { *out = it->second; return GLP_OK; }
+    std::unique_ptr<NttPlan> p(new NttPlan());
+    p->lg = lg;
+    p->lgB = lg < NTT_LGB_MAX ? lg : NTT_LGB_MAX;
+    p->lgA = lg - p->lgB;
+    p->w_n = root_of_unity(lg);
+    p->w_n_inv = inv(p->w_n);
+    p->n_inv = inv((u64)1 << lg);
+    auto table = [](int lgs, bool inverse) {
+        size_t half = lgs > 0 ? ((size_t)1 << (lgs - 1)) : 0;
+        std::vector<u64> t(half);
+        u64 w = root_of_unity(lgs);
+        if (inverse) w = inv(w);
+        u64 x = 1;
+        for (size_t j = 0; j < half; j++) { t[j] = x; x = mul(x, w); }
+        return t;
+    };
+    GLP_TRY(upload(c, table(p->lgB, false), &p->tw_B));
+    GLP_TRY(upload(c, table(p->lgB, true), &p->itw_B));
+    GLP_TRY(upload(c, table(p->lgA, false), &p->tw_A));
+    GLP_TRY(upload(c, table(p->lgA, true), &p->itw_A));
+    *out = p.get();
+    c->ntt_plans[lg] = p.release();
+    return GLP_OK;
+}
+
+int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
+    if (rate_bits < 0 || rate_bits > 4) return set_error(GLP_ERR_UNSUPPORTED, "rate_bits=%d outside 0..4", rate_bits);
+    auto key = std::make_pair(std::make_pair(lg, rate_bits), shift);
+    auto it = c->lde_plans.find(key);
+    if (it != c->lde_plans.end()) { *out = it->second; return GLP_OK; }
+    NttPlan *np;
+    GLP_TRY(get_ntt_plan(c, lg, &np));
+    std::unique_ptr<LdePlan> p(new LdePlan());
+    p->ntt = np; p->rate_bits = rate_bits; p->shift = shift;
+    const int R = 1 << rate_bits;
+    const size_t B = (size_t)1 << np->lgB, A = (size_t)1 << np->lgA;
+    const u64 Wbig = root_of_unity(lg + rate_bits);
+    std::vector<u64> s(R), pre((size_t)R * B);
+    for (int r = 0; r < R; r++) {
+        s[r] = mul(shift, pow(Wbig, (u64)r));
+        u64 sA = pow(s[r], (u64)A);
+        // pre[r][pl] = sA^bitrev_B(pl): walk k2 = 0..B-1 in natural order, scatter to bitrev slot
+        u64 x = 1;
+        for (size_t k2 = 0; k2 < B; k2++) {
+            pre[(size_t)r * B + bitrev32((u32)k2, np->lgB)] = x;
+            x = mul(x, sA);
+        }
+    }
+    GLP_TRY(upload(c, s, &p->s_r));
+    GLP_TRY(upload(c, pre, &p->pre));
+    *out = p.get();
+    c->lde_plans[key] = p.release();
+    return GLP_OK;
+}
+
+void free_plans(glp_ctx *c) {
+    for (auto &kv : c->lde_plans) { (void)hipFree(kv.second->pre); (void)hipFree(kv.second->s_r); delete kv.second; }
+    c->lde_plans.clear();
+    for (auto &kv : c->ntt_plans) {
+        (void)hipFree(kv.second->tw_B); (void)hipFree(kv.second->itw_B); (void)hipFree(kv.second->tw_A); (void)hipFree(kv.second->itw_A);
+        delete kv.second;
+    }
+    c->ntt_plans.clear();
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+constexpr int TPB = 256;
+constexpr int EPT = (1 << NTT_LGB_MAX) / TPB;   // 16 elements per thread in the contiguous tile
+
+__device__ __forceinline__ u64 dev_pow(u64 b, u32 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = mul(r, b); b = sqr(b); e >>= 1; }
+    return r;
+}
+
+// Radix-2 decimation-in-time stages over a tile of 2^lgT elements in LDS (bit-reversed in,
+// natural out).  tw[j] = w_T^j, j < T/2.
+__device__ __forceinline__ void dit_stages(u64 *tile, const u64 *tw, int lgT, int tid) {
+    const int halfT = 1 << (lgT > 0 ? lgT - 1 : 0);
+    for (int s = 0; s < lgT; s++) {
+        const int half = 1 << s;
+        for (int bf = tid; bf < halfT; bf += TPB) {
+            const int lo = bf & (half - 1);
+            const int j = ((bf >> s) << (s + 1)) | lo;
+            const u64 w = tw[lo << (lgT - 1 - s)];
+            const u64 u = tile[j];
+            const u64 v = mul(tile[j + half], w);
+            tile[j] = add(u, v);
+            tile[j + half] = sub(u, v);
+        }
+        __syncthreads();
+    }
+}
+// Radix-2 decimation-in-frequency stages (natural in, bit-reversed out).
+__device__ __forceinline__ void dif_stages(u64 *tile, const u64 *tw, int lgT, int tid) {
+    const int halfT = 1 << (lgT > 0 ? lgT - 1 : 0);
+    for (int s = lgT - 1; s >= 0; s--) {
+        const int half = 1 << s;
+        for (int bf = tid; bf < halfT; bf += TPB) {
+            const int lo = bf & (half - 1);
+            const int j = ((bf >> s) << (s + 1)) | lo;
+            const u64 w = tw[lo << (lgT - 1 - s)];
+            const u64 u = tile[j];
+            const u64 v = tile[j + half];
+            tile[j] = add(u, v);
+            tile[j + half] = mul(sub(u, v), w);
+        }
+        __syncthreads();
+    }
+}
+
+// Forward contiguous pass of the (coset) NTT, all R cosets from one read of the coefficients.
+//   in : coeffs [ncols][n] bit-reversed
+//   out: [ncols][R][n]; block pb of plane r receives  s_r^k1 * w_n^(q2*k1) * DFT_B(c * pre_r)[q2]
+// grid = (n / B, ncols); dynamic LDS = (B + B/2 + 64 + 64 + 16) * 8 bytes
+__global__ __launch_bounds__(TPB) void k_lde_contig(const u64 *__restrict__ coeffs, u64 *__restrict__ out,
+                                                    const u64 *__restrict__ tw_B, const u64 *__restrict__ pre,
+                                                    const u64 *__restrict__ s_r, u64 w_n, int lg, int lgA, int lgB,
+                                                    int R) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int B = 1 << lgB, tid = threadIdx.x;
+    u64 *tile = smem;
+    u64 *tw = tile + B;
+    u64 *T0 = tw + (B >> 1) + 1;
+    u64 *T1 = T0 + 64;
+    u64 *sk = T1 + 64;
+    const u32 pb = blockIdx.x, col = blockIdx.y;
+    const size_t n = (size_t)1 << lg;
+
+    for (int j = tid; j < (B >> 1); j += TPB) tw[j] = tw_B[j];
+    if (lgA > 0) {
+        const u32 k1 = bitrev32(pb, lgA);
+        if (tid < 128) {
+            const u64 base = dev_pow(w_n, k1);
+            if (tid < 64) T0[tid] = dev_pow(base, tid);
+            else T1[tid - 64] = dev_pow(base, (u32)(tid - 64) << 6);
+        } else if (tid < 128 + R) {
+            sk[tid - 128] = dev_pow(s_r[tid - 128], k1);
+        }
+    }
+    u64 c[EPT];
+    const u64 *src = coeffs + (size_t)col * n + (size_t)pb * B;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int pl = tid + TPB * e;
+        c[e] = pl < B ? src[pl] : 0;
+    }
+    __syncthreads();
+    u64 post[EPT];
+    if (lgA > 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int q2 = tid + TPB * e;
+            post[e] = q2 < B ? mul(T1[q2 >> 6], T0[q2 & 63]) : 0;
+        }
+    }
+    for (int r = 0; r < R; r++) {
+        const u64 *pr = pre + (size_t)r * B;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int pl = tid + TPB * e;
+            if (pl < B) tile[pl] = mul(c[e], pr[pl]);
+        }
+        __syncthreads();
+        dit_stages(tile, tw, lgB, tid);
+        u64 *dst = out + ((size_t)col * R + r) * n + (size_t)pb * B;
+        if (lgA > 0) {
+            const u64 skr = sk[r];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int q2 = tid + TPB * e;
+                if (q2 < B) dst[q2] = mul(tile[q2], mul(post[e], skr));
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int q2 = tid + TPB * e;
+                if (q2 < B) dst[q2] = tile[q2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Strided pass: size-A transforms down the rows of an A x B matrix (row stride B), tile = A rows
+// x 16 columns.  DIT (rows bit-reversed in -> natural out) for the forward transform, DIF
+// (natural in -> bit-reversed out) for the inverse.  grid = (B / 16, planes)
+template <bool DIF>
+__global__ __launch_bounds__(TPB) void k_strided(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                 const u64 *__restrict__ tw_A, int lg, int lgA, int lgB) {
+    __shared__ __attribute__((aligned(16))) u64 tile[(1 << NTT_LGA_MAX) * NTT_STRIDED_W];
+    __shared__ u64 tw[1 << (NTT_LGA_MAX - 1)];
+    const int A = 1 << lgA, tid = threadIdx.x;
+    const size_t n = (size_t)1 << lg, B = (size_t)1 << lgB;
+    const size_t base = (size_t)blockIdx.y * n + (size_t)blockIdx.x * NTT_STRIDED_W;
+    const int w = tid & (NTT_STRIDED_W - 1), r0 = tid >> 4;
+    for (int j = tid; j < (A >> 1); j += TPB) tw[j] = tw_A[j];
+    for (int row = r0; row < A; row += TPB / NTT_STRIDED_W) tile[row * NTT_STRIDED_W + w] = in[base + (size_t)row * B + w];
+    __syncthreads();
+    const int nbf = (A >> 1) * NTT_STRIDED_W;
+    if (DIF) {
+        for (int s = lgA - 1; s >= 0; s--) {
+            const int half = 1 << s;
+            for (int idx = tid; idx < nbf; idx += TPB) {
+                const int bf = idx >> 4, lo = bf & (half - 1);
+                const int j = (((bf >> s) << (s + 1)) | lo) * NTT_STRIDED_W + w;
+                const u64 t = tw[lo << (lgA - 1 - s)];
+                const u64 u = tile[j], v = tile[j + half * NTT_STRIDED_W];
+                tile[j] = add(u, v);
+                tile[j + half * NTT_STRIDED_W] = mul(sub(u, v), t);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int s = 0; s < lgA; s++) {
+            const int half = 1 << s;
+            for (int idx = tid; idx < nbf; idx += TPB) {
+                const int bf = idx >> 4, lo = bf & (half - 1);
+                const int j = (((bf >> s) << (s + 1)) | lo) * NTT_STRIDED_W + w;
+                const u64 t = tw[lo << (lgA - 1 - s)];
+                const u64 u = tile[j], v = mul(tile[j + half * NTT_STRIDED_W], t);
+                tile[j] = add(u, v);
+                tile[j + half * NTT_STRIDED_W] = sub(u, v);
+            }
+            __syncthreads();
+        }
+    }
+    for (int row = r0; row < A; row += TPB / NTT_STRIDED_W) out[base + (size_t)row * B + w] = tile[row * NTT_STRIDED_W + w];
+}
+
+// Inverse contiguous pass: block pb (k1 = bitrev_A(pb)) of every column:
+//   x[i2] = in[i2] * (w_n^-k1)^i2 * n^-1 ;  DIF over i2 ;  store in natural tile order (= bit-reversed k2)
+// grid = (n / B, ncols)
+__global__ __launch_bounds__(TPB) void k_intt_contig(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                     const u64 *__restrict__ itw_B, u64 w_n_inv, u64 n_inv, int lg,
+                                                     int lgA, int lgB) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int B = 1 << lgB, tid = threadIdx.x;
+    u64 *tile = smem;
+    u64 *tw = tile + B;
+    u64 *T0 = tw + (B >> 1) + 1;
+    u64 *T1 = T0 + 64;
+    const u32 pb = blockIdx.x, col = blockIdx.y;
+    const size_t n = (size_t)1 << lg;
+    for (int j = tid; j < (B >> 1); j += TPB) tw[j] = itw_B[j];
+    if (lgA > 0 && tid < 128) {
+        const u32 k1 = bitrev32(pb, lgA);
+        const u64 base = dev_pow(w_n_inv, k1);
+        if (tid < 64) T0[tid] = dev_pow(base, tid);
+        else T1[tid - 64] = mul(dev_pow(base, (u32)(tid - 64) << 6), n_inv);
+    }
+    __syncthreads();
+    const size_t off = (size_t)col * n + (size_t)pb * B;
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int i2 = tid + TPB * e;
+        if (i2 < B) {
+            const u64 f = lgA > 0 ? mul(T1[i2 >> 6], T0[i2 & 63]) : n_inv;
+            tile[i2] = mul(in[off + i2], f);
+        }
+    }
+    __syncthreads();
+    dif_stages(tile, tw, lgB, tid);
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int p = tid + TPB * e;
+        if (p < B) out[off + p] = tile[p];
+    }
+}
+
+__global__ void k_bitrev_copy(const u64 *__restrict__ in, u64 *__restrict__ out, int lg) {
+    const size_t n = (size_t)1 << lg;
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t col = blockIdx.y;
+    out[col * n + bitrev32((u32)p, lg)] = in[col * n + p];
+}
+// coset-major slot (r, q) -> natural index q * R + r
+__global__ void k_lde_to_natural(const u64 *__restrict__ in, u64 *__restrict__ out, int lg, int rate_bits) {
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    const size_t pos = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= N) return;
+    const size_t col = blockIdx.y;
+    const size_t r = pos >> lg, q = pos & (((size_t)1 << lg) - 1);
+    out[col * N + (q << rate_bits) + r] = in[col * N + pos];
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static size_t contig_lds_bytes(int lgB) { return (((size_t)1 << lgB) + ((size_t)1 << lgB) / 2 + 1 + 64 + 64 + 16) * sizeof(u64); }
+
+int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift) {
+    if (ncols == 0) return GLP_OK;
+    LdePlan *lp;
+    GLP_TRY(get_lde_plan(c, lg, rate_bits, shift, &lp));
+    const NttPlan *np = lp->ntt;
+    const int R = 1 << rate_bits;
+    if (ncols > 65535u || (u64)ncols * R > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols*2^rate_bits=%llu exceeds grid.y", (unsigned long long)ncols * R);
+    dim3 g1(1u << np->lgA, ncols);
+    hipLaunchKernelGGL(k_lde_contig, g1, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, dev_coeffs, dev_lde, np->tw_B,
+                       lp->pre, lp->s_r, np->w_n, lg, np->lgA, np->lgB, R);
+    GLP_HIP(hipGetLastError());
+    if (np->lgA > 0) {
+        dim3 g2((1u << np->lgB) / NTT_STRIDED_W, ncols * R);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw_A, lg,
+                           np->lgA, np->lgB);
+        GLP_HIP(hipGetLastError());
+    }
+    return GLP_OK;
+}
+
+int ntt_coeffs_to_values(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_values, u32 ncols, int lg) {
+    return lde_coeffs(c, dev_coeffs, dev_values, ncols, lg, 0, 1);
+}
+
+int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg) {
+    if (ncols == 0) return GLP_OK;
+    NttPlan *np;
+    GLP_TRY(get_ntt_plan(c, lg, &np));
+    if (ncols > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols=%u exceeds grid.y", ncols);
+    const u64 *src = dev_values;
+    if (np->lgA > 0) {
+        dim3 g1((1u << np->lgB) / NTT_STRIDED_W, ncols);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs, np->itw_A,
+                           lg, np->lgA, np->lgB);
+        GLP_HIP(hipGetLastError());
+        src = dev_coeffs;
+    }
+    dim3 g2(1u << np->lgA, ncols);
+    hipLaunchKernelGGL(k_intt_contig, g2, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, src, dev_coeffs, np->itw_B,
+                       np->w_n_inv, np->n_inv, lg, np->lgA, np->lgB);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+int bitrev_copy(glp_ctx *c, const u64 *dev_in, u64 *dev_out, u32 ncols, int lg) {
+    if (ncols == 0) return GLP_OK;
+    const size_t n = (size_t)1 << lg;
+    dim3 g((unsigned)((n + 255) / 256), ncols);
+    hipLaunchKernelGGL(k_bitrev_copy, g, dim3(256), 0, c->stream, dev_in, dev_out, lg);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+int lde_to_natural(glp_ctx *c, const u64 *dev_lde, u64 *dev_out, u32 ncols, int lg, int rate_bits) {
+    if (ncols == 0) return GLP_OK;
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    dim3 g((unsigned)((N + 255) / 256), ncols);
+    hipLaunchKernelGGL(k_lde_to_natural, g, dim3(256), 0, c->stream, dev_lde, dev_out, lg, rate_bits);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+}  // namespace glp

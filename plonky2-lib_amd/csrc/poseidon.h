@@ -1,0 +1,82 @@
+// poseidon.h -- plonky2's Poseidon permutation over Goldilocks (width 12, x^7, 4+22+4 rounds,
+// MDS = circulant(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...)) for gfx950 and the host
+// transcript.  One state per lane; the 12x12 MDS has 6-bit entries, so each output row is
+// accumulated unreduced from the 32-bit halves of the inputs and reduced once.
+//
+// Replaces plonky2 `hash/poseidon.rs` + `poseidon_goldilocks.rs` on the prove() path
+// [REF src/ecdsa/gadgets/ecdsa.rs:349]; same primitive the reference calls natively at
+// [REF src/zkdsa/account.rs:165, src/smt/goldilocks_poseidon/mod.rs:165].
+#pragma once
+#include "glf.h"
+#include "poseidon_rc.inc"
+
+namespace pos {
+using namespace glf;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const u64 RC[360] = { GLP_POSEIDON_RC_LIST };
+#else
+static const u64 RC[360] = { GLP_POSEIDON_RC_LIST };
+#endif
+
+GLF_HD u64 sbox7(u64 x) {
+    u64 x2 = sqr(x), x4 = sqr(x2), x3 = mul(x, x2);
+    return mul(x3, x4);
+}
+
+// out[r] = sum_i s[(i+r)%12]*CIRC[i] + s[r]*DIAG[r]   (plonky2 `mds_row_shf`)
+GLF_HD void mds_layer(u64 s[12]) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (u64)lo[(i + r) % 12] * C[i];
+            ah += (u64)hi[(i + r) % 12] * C[i];
+        }
+        if (r == 0) { al += (u64)lo[0] * 8; ah += (u64)hi[0] * 8; }
+        // value = al + ah * 2^32, both < 2^42
+        u64 l = al + (ah << 32);
+        u32 h = (u32)(ah >> 32) + (l < al ? 1u : 0u);
+        s[r] = reduce96(l, h);
+    }
+}
+
+GLF_HD void permute(u64 s[12]) {
+    int rc = 0;
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7(add(s[i], RC[rc + i]));
+        rc += 12;
+        mds_layer(s);
+    }
+    for (int r = 0; r < 22; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[rc + i]);
+        rc += 12;
+        s[0] = sbox7(s[0]);
+        mds_layer(s);
+    }
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7(add(s[i], RC[rc + i]));
+        rc += 12;
+        mds_layer(s);
+    }
+}
+
+// hashing.rs `compress` (= Hasher::two_to_one): perm(l || r || 0000)[0..4]
+GLF_HD void two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = l[i]; s[4 + i] = r[i]; s[8 + i] = 0; }
+    permute(s);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = s[i];
+}
+
+}  // namespace pos

@@ -1,0 +1,147 @@
+"""GPU parity tests for the commitment half of prove(): Poseidon, NTT/iNTT/LDE and
+PolynomialBatch (from_values / from_coeffs -> coefficients, leaves, every Merkle digest, cap, paths),
+HIP library (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import plonky2_lib_amd as glp
+
+pytestmark = pytest.mark.gpu
+P = glp.P
+KAT = [4330397376401421145, 14124799381142128323, 8742572140681234676, 14345658006221440202]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = glp.Context(0)
+    yield c
+    c.close()
+
+
+def test_poseidon_kat_on_gpu(ctx):
+    # [REF src/zkdsa/circuits/mod.rs:85-101]
+    out = ctx.poseidon_permute(np.zeros((3, 12), np.uint64))
+    for row in out:
+        assert [int(x) for x in row[:4]] == KAT
+
+
+def test_poseidon_parity(ctx, oracle):
+    rng = np.random.default_rng(11)
+    st = oracle.rand_field(rng, (1000, 12))
+    st[0] = P - 1
+    st[1] = 0xFFFFFFFF
+    st[2] = 0xFFFFFFFF00000000
+    st[3, :] = [0, 1, 2, P - 1, P - 2, 1 << 32, (1 << 32) - 1, (1 << 63), 3, 5, 7, 11]
+    got = ctx.poseidon_permute(st)
+    for i in range(st.shape[0]):
+        assert (got[i] == oracle.poseidon_permute(st[i])).all(), i
+
+
+@pytest.mark.parametrize("lg", [0, 1, 2, 5, 8, 11, 12, 13, 15, 16])
+def test_fft_ifft_parity(ctx, oracle, lg):
+    rng = np.random.default_rng(100 + lg)
+    ncols = 3
+    a = oracle.rand_field(rng, (ncols, 1 << lg))
+    f = ctx.fft(a)
+    i = ctx.ifft(a)
+    for c in range(ncols):
+        assert (f[c] == oracle.fft(a[c])).all()
+        assert (i[c] == oracle.ifft(a[c])).all()
+    assert (ctx.ifft(f) == a).all()
+
+
+@pytest.mark.parametrize("lg,rb,shift", [(0, 3, 7), (3, 3, 7), (6, 1, 7), (9, 3, 7 ** 16 % P), (12, 3, 7), (13, 3, 7), (14, 2, 49), (16, 3, 7)])
+def test_lde_parity(ctx, oracle, lg, rb, shift):
+    rng = np.random.default_rng(200 + lg)
+    c = oracle.rand_field(rng, (2, 1 << lg))
+    got = ctx.lde(c, rb, shift)
+    for k in range(2):
+        assert (got[k] == oracle.lde(c[k], rb, shift)).all()
+
+
+def _check_batch(oracle, b, ref, probe):
+    assert (b.cap() == ref.cap).all()
+    assert (b.coeffs() == ref.coeffs).all()
+    assert (b.digests() == ref.digests).all()
+    nl = ref.leaves.shape[0]
+    for j in probe:
+        j %= nl
+        assert (b.leaf(j) == ref.leaves[j]).all()
+        sib = b.prove(j)
+        assert (sib == ref.prove(j)).all()
+        assert oracle.merkle_verify(ref.leaves[j], j, ref.cap, sib)
+
+
+@pytest.mark.parametrize("ncols,lg,rb,ch", [
+    (3, 4, 3, 4),      # <= 4 columns: hash_or_noop copies the leaf
+    (4, 2, 3, 5),      # cap_height == log2(leaves): cap = leaf digests
+    (5, 5, 3, 2),      # one partial sponge chunk
+    (8, 6, 3, 4),      # exactly one full chunk
+    (9, 3, 3, 0),      # cap_height 0 -> single root
+    (135, 10, 3, 4),   # standard_recursion_config wire count
+    (136, 13, 3, 4),   # standard_ecc_config wire count, two-pass NTT
+    (20, 14, 3, 4),    # zs + partial products batch
+    (16, 12, 3, 4),    # quotient chunks batch
+    (2, 15, 1, 3),
+])
+def test_batch_from_values_parity(ctx, oracle, ncols, lg, rb, ch):
+    rng = np.random.default_rng(1000 * ncols + lg)
+    vals = oracle.rand_field(rng, (ncols, 1 << lg))
+    ref = oracle.batch_from_values(vals, rb, ch)
+    b = ctx.batch_from_values(vals, rb, ch)
+    _check_batch(oracle, b, ref, [0, 1, 7, 12345, (1 << (lg + rb)) - 1])
+    b.free()
+
+
+@pytest.mark.parametrize("ncols,lg", [(16, 9), (7, 13)])
+def test_batch_from_coeffs_parity(ctx, oracle, ncols, lg):
+    rng = np.random.default_rng(77 + lg)
+    co = oracle.rand_field(rng, (ncols, 1 << lg))
+    ref = oracle.batch_from_coeffs(co, 3, 4)
+    b = ctx.batch_from_coeffs(co, 3, 4)
+    _check_batch(oracle, b, ref, [0, 3, 999, (1 << (lg + 3)) - 1])
+    b.free()
+
+
+def test_golden_fixture(ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_5x32.npz"))
+    b = ctx.batch_from_values(g["values"], 3, 2)
+    assert (b.cap() == g["cap"]).all() and (b.coeffs() == g["coeffs"]).all()
+    assert (b.digests() == g["digests"]).all()
+    b.free()
+
+
+def test_headline_shape_properties(ctx, oracle):
+    """136 columns x 2^16 rows is past what the oracle checks in seconds per digest, so use
+    size-independent properties: iNTT then NTT is the identity, sampled LDE points equal a Horner
+    evaluation, sampled Merkle paths recompute to the cap."""
+    rng = np.random.default_rng(5)
+    ncols, lg = 136, 16
+    vals = oracle.rand_field(rng, (ncols, 1 << lg))
+    b = ctx.batch_from_values(vals, 3, 4)
+    co = b.coeffs(0, 2)
+    assert (ctx.fft(co) == vals[:2]).all()
+    cap = b.cap()
+    br = oracle.bitrev_perm(lg + 3)
+    W = oracle.root_of_unity(lg + 3)
+    for j in (0, 5, 77777, (1 << (lg + 3)) - 1):
+        leaf = b.leaf(j)
+        assert oracle.merkle_verify(leaf, j, cap, b.prove(j))
+        x = 7 * pow(W, int(br[j]), P) % P
+        for c in (0, 1):
+            acc = 0
+            for v in co[c][::-1]:
+                acc = (acc * x + int(v)) % P
+            assert acc == int(leaf[c])
+    b.free()
+
+
+def test_errors(ctx):
+    with pytest.raises(glp.GlpError):
+        ctx.batch_from_values(np.zeros((2, 8), np.uint64), 3, 7)      # cap_height > log2(leaves)
+    with pytest.raises(glp.GlpError):
+        ctx.batch_from_values(np.zeros((2, 12), np.uint64), 3, 1)     # not a power of two
+    with pytest.raises(glp.GlpError) as e:
+        glp.Batch._make_dev(ctx, "glp_batch_from_values_device", 8, 1, 21, 3, 4)
+    assert e.value.code == -3

@@ -73,6 +73,10 @@ GLP_API int glp_ifft(glp_ctx *ctx, uint64_t *cols, uint32_t ncols, uint32_t log_
 GLP_API int glp_lde(glp_ctx *ctx, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
             uint64_t shift, uint64_t *out);
 
+/* Synthetic-trace helper for benchmarks: dev_out[i] = SplitMix64(seed, i) folded into [0, p)
+ * (z >= p ? z - p : z).  Lets bench.py create HBM-resident inputs without a PCIe copy. */
+GLP_API int glp_fill_random_device(glp_ctx *ctx, uint64_t *dev_out, size_t count, uint64_t seed);
+
 /* ---- PolynomialBatch (fri/oracle.rs) ----------------------------------------------------------
  * glp_batch_from_values  = PolynomialBatch::from_values  (ifft, lde x 2^rate_bits on the coset 7*H,
  *                          transpose + bit-reverse, MerkleTree::new(leaves, cap_height))

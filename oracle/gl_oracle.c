@@ -73,10 +73,11 @@ static inline u64 sbox7(u64 x) {
     return gl_mul(x3, x4);
 }
 static inline void mds_layer(u64 s[12]) {
-    u64 o[12];
+    u64 o[12], d[24];
+    memcpy(d, s, 96); memcpy(d + 12, s, 96);      /* d[i + r] == s[(i + r) % 12] */
     for (int r = 0; r < 12; r++) { /* mds_row_shf */
         u128 acc = 0;
-        for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * MDS_CIRC[i];
+        for (int i = 0; i < 12; i++) acc += (u128)d[i + r] * MDS_CIRC[i];
         acc += (u128)s[r] * MDS_DIAG[r];
         o[r] = gl_reduce128(acc);
     }

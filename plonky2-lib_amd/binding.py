@@ -68,6 +68,7 @@ def load_library():
         "glp_ctx_stage_count": [vp],
         "glp_ctx_stage_get": [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_double)],
         "glp_poseidon_permute": [vp, vp, sz],
+        "glp_fill_random_device": [vp, vp, sz, u64],
         "glp_fft": [vp, vp, u32, u32],
         "glp_ifft": [vp, vp, u32, u32],
         "glp_lde": [vp, vp, u32, u32, u32, u64, vp],
@@ -89,6 +90,17 @@ def load_library():
     L.glp_batch_free.restype = None
     _lib = L
     return L
+
+
+def splitmix_field(seed, count, offset=0):
+    """numpy twin of glp_fill_random_device (same values for the same seed)."""
+    with np.errstate(over="ignore"):
+        i = np.arange(offset + 1, offset + count + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        return np.where(z >= np.uint64(P), z - np.uint64(P), z)
 
 
 def _chk(rc):
@@ -174,6 +186,9 @@ class Context:
         out = np.empty((a.shape[0], a.shape[1] << rate_bits), np.uint64)
         _chk(load_library().glp_lde(self._h, _p(a), a.shape[0], int(a.shape[1]).bit_length() - 1, rate_bits, shift, _p(out)))
         return out
+
+    def fill_random_device(self, dev_ptr, count, seed):
+        _chk(load_library().glp_fill_random_device(self._h, C.c_void_p(dev_ptr), count, seed))
 
     # -- PolynomialBatch
     def batch_from_values(self, values, rate_bits=3, cap_height=4):

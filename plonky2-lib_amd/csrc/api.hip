@@ -237,8 +237,28 @@ int glp_lde(glp_ctx *c, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, 
     return GLP_OK;
 }
 
-// ------------------------------------------------------------------------------------------ PolynomialBatch
 }  // extern "C"
+
+__global__ void k_fill_random(u64 *out, size_t count, u64 seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = glf::canon(z);
+}
+
+extern "C" int glp_fill_random_device(glp_ctx *c, uint64_t *dev_out, size_t count, uint64_t seed) {
+    GLP_REQUIRE(c && (dev_out || !count), "null argument");
+    GLP_TRY(bind(c));
+    if (!count) return GLP_OK;
+    hipLaunchKernelGGL(k_fill_random, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, dev_out, count, seed);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PolynomialBatch
 
 namespace glp {
 

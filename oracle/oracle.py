@@ -239,3 +239,72 @@ class Challenger:
 
 def set_threads(n): lib().glo_set_threads(int(n))
 def max_threads(): return lib().glo_max_threads()
+
+
+# ---------------------------------------------------------------- prove / verify (gl_prover_oracle.c)
+class _Gate(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("selector_index", C.c_uint32), ("group_start", C.c_uint32),
+                ("group_end", C.c_uint32), ("row", C.c_uint32), ("num_constraints", C.c_uint32),
+                ("p0", C.c_uint32), ("p1", C.c_uint32)]
+
+
+class _Circuit(C.Structure):
+    _fields_ = [("degree_bits", C.c_uint32), ("num_wires", C.c_uint32), ("num_routed_wires", C.c_uint32),
+                ("num_constants", C.c_uint32), ("num_selectors", C.c_uint32), ("num_challenges", C.c_uint32),
+                ("quotient_degree_factor", C.c_uint32), ("num_partial_products", C.c_uint32),
+                ("num_gate_constraints", C.c_uint32), ("rate_bits", C.c_uint32), ("cap_height", C.c_uint32),
+                ("proof_of_work_bits", C.c_uint32), ("num_query_rounds", C.c_uint32), ("num_reductions", C.c_uint32),
+                ("reduction_arity_bits", C.c_uint32 * 16), ("num_gates", C.c_uint32), ("num_public_inputs", C.c_uint32),
+                ("gates", C.POINTER(_Gate)), ("k_is", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
+                ("constants", C.c_void_p), ("sigmas", C.c_void_p)]
+
+
+class OracleCircuit:
+    """Wraps a plonky2_lib_amd.synth.Circuit (plain attribute bag) for the C oracle."""
+
+    def __init__(self, c):
+        self.c = c
+        self._k = _a(c.k_is); self._const = _a(c.constants); self._sig = _a(c.sigmas)
+        self._gates = (_Gate * len(c.gates))()
+        for i, g in enumerate(c.gates):
+            for f in ("type", "selector_index", "group_start", "group_end", "row", "num_constraints", "p0", "p1"):
+                setattr(self._gates[i], f, int(g[f]))
+        s = _Circuit()
+        for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
+                  "quotient_degree_factor", "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
+                  "proof_of_work_bits", "num_query_rounds"):
+            setattr(s, f, int(getattr(c, f)))
+        s.num_reductions = len(c.reduction_arity_bits)
+        for i, a in enumerate(c.reduction_arity_bits):
+            s.reduction_arity_bits[i] = int(a)
+        s.num_gates = len(c.gates)
+        s.num_public_inputs = int(len(c.public_inputs))
+        s.gates = C.cast(self._gates, C.POINTER(_Gate))
+        s.k_is = self._k.ctypes.data; s.constants = self._const.ctypes.data; s.sigmas = self._sig.ctypes.data
+        self.s = s
+        L = lib()
+        L.glo_proof_words.restype = C.c_size_t
+        self.cs_cap = np.empty((1 << c.cap_height, 4), np.uint64)
+        L.glo_constants_sigmas_cap(C.byref(s), _p(self.cs_cap))
+        if getattr(c, "circuit_digest", None) is None:
+            c.circuit_digest = circuit_digest(self.cs_cap, c.degree_bits)
+        for i in range(4):
+            s.circuit_digest[i] = int(c.circuit_digest[i])
+        self.proof_words = L.glo_proof_words(C.byref(s))
+
+    def prove(self, wires=None, public_inputs=None):
+        w = _a(self.c.wires if wires is None else wires)
+        pi = _a(self.c.public_inputs if public_inputs is None else public_inputs)
+        proof = np.zeros(self.proof_words, np.uint64)
+        rc = lib().glo_prove(C.byref(self.s), _p(w), _p(pi) if pi.size else None, _p(proof))
+        return rc, proof
+
+    def verify(self, proof):
+        return lib().glo_verify(C.byref(self.s), _p(self.cs_cap), _p(_a(proof)))
+
+
+def circuit_digest(constants_sigmas_cap, degree_bits):
+    """plonk/circuit_builder.rs build(): hash_no_pad(cap.flatten() ++ hash_pad(domain_separator = []) ++ [degree_bits])."""
+    ds = hash_pad(np.zeros(0, np.uint64))
+    parts = np.concatenate([_a(constants_sigmas_cap).reshape(-1), ds, np.array([degree_bits], np.uint64)])
+    return hash_no_pad(parts)

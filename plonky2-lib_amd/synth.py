@@ -1,0 +1,285 @@
+"""Synthetic plonky2 circuits + satisfying witnesses (host side, numpy).
+
+The reference's circuits are built by Rust code (`CircuitBuilder` + the gadget traits of
+src/{ecdsa,hash,smt,zkdsa}) that cannot run here, so tests and bench.py use stand-ins with the same
+*shape*: `standard_ecc_config` (136 wires / 80 routed, [REF src/ecdsa/gadgets/ecdsa.rs:476-483]) or
+`standard_recursion_config` (135 / 80), rows of ArithmeticGate / ConstantGate / PublicInputGate /
+NoopGate and the reference's own three u32 gates [REF src/u32/gates/*.rs], copy constraints, and a
+witness that satisfies every gate.  What `builder.build::<C>()` would produce for the prover is
+restated: gates sorted by (degree, id), `selector_polynomials` grouping, k_is = 7^i, sigma values
+k_is[col'] * w^row'.
+
+Nothing here touches the GPU or the oracle.
+"""
+import numpy as np
+
+from . import gl_numpy as gl
+
+P = gl.P
+
+GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
+GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_U32, GATE_UNINTERLEAVE_B32 = 5, 6, 7
+
+# (degree, id string as plonky2's `Gate::id` prints it) -- the build() sort key
+_GATE_META = {
+    GATE_NOOP: (0, "NoopGate"),
+    GATE_CONSTANT: (1, "ConstantGate {{ num_consts: {p0} }}"),
+    GATE_PUBLIC_INPUT: (1, "PublicInputGate"),
+    GATE_ARITHMETIC: (3, "ArithmeticGate {{ num_ops: {p0} }}"),
+    GATE_U32_INTERLEAVE: (2, "U32InterleaveGate {{ num_ops: {p0} }}"),
+    GATE_UNINTERLEAVE_U32: (2, "UninterleaveToU32Gate {{ num_ops: {p0} }}"),
+    GATE_UNINTERLEAVE_B32: (2, "UninterleaveToB32Gate {{ num_ops: {p0} }}"),
+}
+
+
+def gate_num_constraints(t, p0):
+    return {GATE_NOOP: 0, GATE_CONSTANT: p0, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: p0,
+            GATE_U32_INTERLEAVE: p0 * 34, GATE_UNINTERLEAVE_U32: p0 * 67, GATE_UNINTERLEAVE_B32: p0 * 67}[t]
+
+
+class Config:
+    """plonk/circuit_data.rs `CircuitConfig` presets the reference selects in code."""
+
+    def __init__(self, num_wires, num_routed_wires, num_constants=2, num_challenges=2, max_quotient_degree_factor=8,
+                 rate_bits=3, cap_height=4, proof_of_work_bits=16, num_query_rounds=28, arity_bits=4, final_poly_bits=5):
+        self.num_wires, self.num_routed_wires, self.num_constants = num_wires, num_routed_wires, num_constants
+        self.num_challenges, self.max_quotient_degree_factor = num_challenges, max_quotient_degree_factor
+        self.rate_bits, self.cap_height, self.proof_of_work_bits = rate_bits, cap_height, proof_of_work_bits
+        self.num_query_rounds, self.arity_bits, self.final_poly_bits = num_query_rounds, arity_bits, final_poly_bits
+
+    @classmethod
+    def standard_recursion_config(cls, **kw):
+        return cls(135, 80, **kw)
+
+    @classmethod
+    def standard_ecc_config(cls, **kw):
+        return cls(136, 80, **kw)
+
+    def reduction_arity_bits(self, degree_bits):
+        """fri/reduction_strategies.rs ConstantArityBits(arity_bits, final_poly_bits)."""
+        out, d = [], degree_bits
+        while d > self.final_poly_bits and d + self.rate_bits - self.arity_bits >= self.cap_height:
+            out.append(self.arity_bits)
+            d -= self.arity_bits
+        return out
+
+
+class Circuit:
+    """Flat CommonCircuitData + ProverOnlyCircuitData (what prove() reads) and a witness."""
+    pass
+
+
+def _selector_groups(gates, max_degree):
+    """gates/selectors.rs `selector_polynomials`: returns (selector_indices, groups)."""
+    num_gates = len(gates)
+    max_gate_degree = gates[-1][0]
+    if max_gate_degree + num_gates - 1 <= max_degree:
+        return [0] * num_gates, [(0, num_gates)]
+    groups, start = [], 0
+    while start < num_gates:
+        size = 0
+        while start + size < num_gates and size + gates[start + size][0] < max_degree:
+            size += 1
+        groups.append((start, start + size))
+        start += size
+    sel = []
+    for i in range(num_gates):
+        sel.append(next(k for k, (a, b) in enumerate(groups) if a <= i < b))
+    return sel, groups
+
+
+class Builder:
+    def __init__(self, config, log_n, seed=0):
+        self.cfg, self.log_n, self.n = config, log_n, 1 << log_n
+        self.rng = np.random.default_rng(seed)
+        n, nw, nr = self.n, config.num_wires, config.num_routed_wires
+        self.row_gate = np.zeros(n, dtype=np.int64)            # per row: key into self.gate_kinds
+        self.gate_kinds = {}                                   # (type, p0) -> key
+        self.gate_consts = np.zeros((config.num_constants, n), dtype=np.uint64)
+        self.wires = gl.rand(self.rng, (nw, n))                # unconstrained cells stay random
+        self.sig_row = np.tile(np.arange(n, dtype=np.int64), (nr, 1))
+        self.sig_col = np.tile(np.arange(nr, dtype=np.int64)[:, None], (1, n))
+        self.public_inputs = np.zeros(0, dtype=np.uint64)
+        self._kind(GATE_NOOP, 0)
+
+    def _kind(self, t, p0):
+        return self.gate_kinds.setdefault((t, p0), len(self.gate_kinds))
+
+    def set_rows(self, rows, t, p0):
+        self.row_gate[rows] = self._kind(t, p0)
+
+    def connect_pairs(self, rows_a, col_a, rows_b, col_b):
+        """2-cycles between fresh cells (rows_a[i], col_a) <-> (rows_b[i], col_b)."""
+        self.sig_row[col_a, rows_a], self.sig_col[col_a, rows_a] = rows_b, col_b
+        self.sig_row[col_b, rows_b], self.sig_col[col_b, rows_b] = rows_a, col_a
+
+    def connect_cycle(self, rows, cols):
+        """One cycle through fresh cells (rows[i], cols[i]) in the given order."""
+        rows, cols = np.asarray(rows), np.asarray(cols)
+        self.sig_row[cols, rows] = np.roll(rows, -1)
+        self.sig_col[cols, rows] = np.roll(cols, -1)
+
+    def build(self):
+        cfg, n, lg = self.cfg, self.n, self.log_n
+        c = Circuit()
+        kinds = sorted(self.gate_kinds.items(), key=lambda kv: (_GATE_META[kv[0][0]][0], _GATE_META[kv[0][0]][1].format(p0=kv[0][1])))
+        gates = [(_GATE_META[t][0], t, p0) for (t, p0), _ in kinds]
+        key_to_index = {key: i for i, (_, key) in enumerate(kinds)}
+        sel_idx, groups = _selector_groups(gates, cfg.max_quotient_degree_factor + 1)
+        num_selectors = len(groups)
+        gate_index = np.array([key_to_index[k] for k in self.row_gate], dtype=np.int64)
+        consts = np.zeros((num_selectors + cfg.num_constants, n), dtype=np.uint64)
+        for g in range(num_selectors):
+            a, b = groups[g]
+            in_group = (gate_index >= a) & (gate_index < b)
+            consts[g] = np.where(in_group, gate_index.astype(np.uint64), np.uint64(0xFFFFFFFF)) if num_selectors > 1 \
+                else gate_index.astype(np.uint64)
+        consts[num_selectors:] = self.gate_consts
+        c.gates = [dict(type=t, p0=p0, p1=0, selector_index=sel_idx[i], group_start=groups[sel_idx[i]][0],
+                        group_end=groups[sel_idx[i]][1], row=i, num_constraints=gate_num_constraints(t, p0))
+                   for i, (_, t, p0) in enumerate(gates)]
+        c.degree_bits = lg
+        c.num_wires, c.num_routed_wires = cfg.num_wires, cfg.num_routed_wires
+        c.num_constants, c.num_selectors = consts.shape[0], num_selectors
+        c.num_challenges, c.quotient_degree_factor = cfg.num_challenges, cfg.max_quotient_degree_factor
+        c.num_partial_products = -(-cfg.num_routed_wires // c.quotient_degree_factor) - 1
+        c.num_gate_constraints = max(g["num_constraints"] for g in c.gates)
+        c.rate_bits, c.cap_height = cfg.rate_bits, cfg.cap_height
+        c.proof_of_work_bits, c.num_query_rounds = cfg.proof_of_work_bits, cfg.num_query_rounds
+        c.reduction_arity_bits = cfg.reduction_arity_bits(lg)
+        c.k_is = gl.powers(7, cfg.num_routed_wires)
+        subgroup = gl.powers(gl.root_of_unity(lg), n)
+        c.constants = consts
+        c.sigmas = gl.mul(c.k_is[self.sig_col], subgroup[self.sig_row])
+        c.wires = self.wires
+        c.public_inputs = self.public_inputs
+        c.circuit_digest = None     # filled by the prover library / the oracle (needs the constants+sigmas cap)
+        return c
+
+
+def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, num_const_rows=4, num_noop_rows=3):
+    """ECDSA-shaped stand-in: one PublicInputGate row, a few ConstantGate rows, ArithmeticGate rows
+    (20 ops wide for 80 routed wires) chained through copy constraints, NoopGate padding."""
+    cfg = config or Config.standard_ecc_config()
+    b = Builder(cfg, log_n, seed)
+    n = b.n
+    num_ops = cfg.num_routed_wires // 4
+    pi = np.asarray(public_inputs, dtype=np.uint64)
+    b.public_inputs = pi
+    if pi_hash is None:
+        if len(pi):
+            raise ValueError("pass pi_hash = hash_no_pad(public_inputs) when public inputs are non-empty")
+        pi_hash = np.zeros(4, np.uint64)
+    need_const_rows = max(num_const_rows, 2)
+    if n < 1 + need_const_rows + num_noop_rows + 2:
+        raise ValueError("log_n too small")
+    row_pi = 0
+    rows_c = np.arange(1, 1 + need_const_rows)
+    rows_a = np.arange(1 + need_const_rows, n - num_noop_rows)
+    b.set_rows(np.array([row_pi]), GATE_PUBLIC_INPUT, 0)
+    b.set_rows(rows_c, GATE_CONSTANT, cfg.num_constants)
+    b.set_rows(rows_a, GATE_ARITHMETIC, num_ops)
+    na = len(rows_a)
+    # ConstantGate rows: wire i = constant i.  Rows 0,1 carry the public-input hash.
+    cvals = gl.rand(b.rng, (cfg.num_constants, need_const_rows))
+    cvals[0, 0], cvals[1, 0], cvals[0, 1], cvals[1, 1] = pi_hash[0], pi_hash[1], pi_hash[2], pi_hash[3]
+    b.gate_consts[:, rows_c] = cvals
+    b.wires[:cfg.num_constants, rows_c] = cvals
+    # PublicInputGate wires 0..3 = hash, copy-constrained to the constant cells
+    b.wires[:4, row_pi] = pi_hash
+    for k in range(4):
+        b.connect_pairs(np.array([row_pi]), k, np.array([rows_c[k // 2]]), k % 2)
+    # ArithmeticGate rows: per-row constants c0, c1; out_j = c0*m0*m1 + c1*addend; out_j -> addend_{j+1}
+    c01 = gl.rand(b.rng, (2, na))
+    b.gate_consts[0, rows_a], b.gate_consts[1, rows_a] = c01[0], c01[1]
+    shared = gl.rand(b.rng, 1)[0]
+    b.wires[1, rows_a] = shared                               # m1 of op 0: one big cycle over all rows
+    b.connect_cycle(rows_a, np.full(na, 1))
+    # remaining ConstantGate cells feed m0 of op 0 of the first arithmetic rows
+    extra = [(r, k) for r in range(2, need_const_rows) for k in range(cfg.num_constants)]
+    for t, (r, k) in enumerate(extra[:na]):
+        b.wires[0, rows_a[t]] = cvals[k, r]
+        b.connect_pairs(np.array([rows_c[r]]), k, np.array([rows_a[t]]), 0)
+    for j in range(num_ops):
+        m0, m1, ad = b.wires[4 * j, rows_a], b.wires[4 * j + 1, rows_a], b.wires[4 * j + 2, rows_a]
+        out = gl.add(gl.mul(gl.mul(m0, m1), c01[0]), gl.mul(ad, c01[1]))
+        b.wires[4 * j + 3, rows_a] = out
+        if j + 1 < num_ops:
+            b.wires[4 * (j + 1) + 2, rows_a] = out
+            b.connect_pairs(rows_a, 4 * j + 3, rows_a, 4 * (j + 1) + 2)
+    return b.build()
+
+
+def u32_circuit(log_n=6, config=None, seed=2):
+    """Exercises the reference's own gates [REF src/u32/gates/interleave_u32.rs, uninterleave_to_u32.rs,
+    uninterleave_to_b32.rs] next to arithmetic rows: x -> interleave(x), y -> interleave(y), then
+    uninterleave(interleave(x) + interleave(y)) gives the AND (odds) and XOR (evens) bits -- the
+    one-add XOR/AND trick of [REF src/u32/interleaved_u32.rs:145-179]."""
+    cfg = config or Config.standard_recursion_config()
+    b = Builder(cfg, log_n, seed)
+    n = b.n
+    n_il = min(cfg.num_wires // 34, cfg.num_routed_wires // 2)     # U32InterleaveGate::num_ops
+    n_ul = min(cfg.num_wires // 67, cfg.num_routed_wires // 3)     # UninterleaveTo*Gate::num_ops
+    num_ops = cfg.num_routed_wires // 4
+    rows_il = np.arange(1, 1 + 4)
+    rows_u32 = np.arange(5, 5 + 2)
+    rows_b32 = np.arange(7, 7 + 2)
+    rows_c = np.arange(9, 11)
+    rows_a = np.arange(11, n - 2)
+    b.set_rows(np.array([0]), GATE_PUBLIC_INPUT, 0)
+    b.set_rows(rows_il, GATE_U32_INTERLEAVE, n_il)
+    b.set_rows(rows_u32, GATE_UNINTERLEAVE_U32, n_ul)
+    b.set_rows(rows_b32, GATE_UNINTERLEAVE_B32, n_ul)
+    b.set_rows(rows_c, GATE_CONSTANT, cfg.num_constants)
+    b.set_rows(rows_a, GATE_ARITHMETIC, num_ops)
+    b.wires[:4, 0] = 0
+    b.gate_consts[:, rows_c] = 0
+    b.wires[:cfg.num_constants, rows_c] = 0
+    for k in range(4):
+        b.connect_pairs(np.array([0]), k, np.array([rows_c[k // 2]]), k % 2)
+
+    def interleave(x):
+        r = 0
+        for i in range(32):
+            r |= ((x >> i) & 1) << (2 * i)
+        return r
+
+    # interleave rows
+    for r in rows_il:
+        for op in range(n_il):
+            x = int(b.rng.integers(0, 1 << 32))
+            b.wires[2 * op, r] = x
+            b.wires[2 * op + 1, r] = interleave(x)
+            for k in range(32):     # big-endian bits
+                b.wires[2 * n_il + 32 * op + k, r] = (x >> (31 - k)) & 1
+    # uninterleave rows: input = interleave(x) + interleave(y) (< 2^64, in the field by construction of the test values)
+    for rows, b32 in ((rows_u32, False), (rows_b32, True)):
+        for r in rows:
+            for op in range(n_ul):
+                x, y = int(b.rng.integers(0, 1 << 31)), int(b.rng.integers(0, 1 << 31))
+                v = interleave(x) + interleave(y)
+                b.wires[3 * op, r] = v
+                bits = [(v >> (63 - k)) & 1 for k in range(64)]
+                ev = sum(bits[2 * j] << (31 - j) for j in range(32))
+                od = sum(bits[2 * j + 1] << (31 - j) for j in range(32))
+                if b32:
+                    ev, od = interleave(ev), interleave(od)
+                else:
+                    assert od == (x ^ y) and ev == (x & y)
+                b.wires[3 * op + 1, r], b.wires[3 * op + 2, r] = ev, od
+                for k in range(64):
+                    b.wires[3 * n_ul + 64 * op + k, r] = bits[k]
+    # arithmetic rows as in arith_circuit (no cross-row wiring except the shared m1 cycle)
+    na = len(rows_a)
+    c01 = gl.rand(b.rng, (2, na))
+    b.gate_consts[0, rows_a], b.gate_consts[1, rows_a] = c01[0], c01[1]
+    b.wires[1, rows_a] = gl.rand(b.rng, 1)[0]
+    b.connect_cycle(rows_a, np.full(na, 1))
+    for j in range(num_ops):
+        m0, m1, ad = b.wires[4 * j, rows_a], b.wires[4 * j + 1, rows_a], b.wires[4 * j + 2, rows_a]
+        out = gl.add(gl.mul(gl.mul(m0, m1), c01[0]), gl.mul(ad, c01[1]))
+        b.wires[4 * j + 3, rows_a] = out
+        if j + 1 < num_ops:
+            b.wires[4 * (j + 1) + 2, rows_a] = out
+            b.connect_pairs(rows_a, 4 * j + 3, rows_a, 4 * (j + 1) + 2)
+    return b.build()

@@ -1,0 +1,68 @@
+"""The oracle's prove()/verify() restatement, checked through the relation the reference's own tests
+assert: verify(prove(witness)) accepts [REF src/ecdsa/gadgets/nonnative.rs:854-879 and the other 42
+`.prove(` call sites], a tampered proof or an unsatisfied witness is rejected
+[REF src/ecdsa/gadgets/curve.rs:300-326 is the reference's negative test]."""
+import numpy as np
+import pytest
+
+import plonky2_lib_amd.synth as synth
+
+
+@pytest.mark.parametrize("lg,cfg", [(5, "ecc"), (8, "rec")])
+def test_prove_verify_arith(oracle, lg, cfg):
+    config = synth.Config.standard_ecc_config() if cfg == "ecc" else synth.Config.standard_recursion_config()
+    c = synth.arith_circuit(lg, config, seed=lg)
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    assert (proof < np.uint64(oracle.P)).all()
+    # determinism
+    rc2, proof2 = oc.prove()
+    assert (proof == proof2).all()
+    for pos in (0, 200, len(proof) // 2, len(proof) - 1):
+        bad = proof.copy(); bad[pos] = np.uint64((int(bad[pos]) + 1) % oracle.P)
+        assert oc.verify(bad) != 0, pos
+
+
+def test_unsatisfied_witness_is_rejected(oracle):
+    c = synth.arith_circuit(6, seed=3)
+    oc = oracle.OracleCircuit(c)
+    w = c.wires.copy(); w[3, 30] = np.uint64((int(w[3, 30]) + 1) % oracle.P)      # break an ArithmeticGate output
+    rc, proof = oc.prove(wires=w)
+    assert oc.verify(proof) != 0
+    w = c.wires.copy(); w[1, 40] = np.uint64((int(w[1, 40]) + 1) % oracle.P)      # break a copy constraint only
+    w[3, 40] = 0  # (gate constraint is broken too unless recomputed; keep it simple: both must be caught)
+    rc, proof = oc.prove(wires=w)
+    assert oc.verify(proof) != 0
+
+
+def test_public_inputs(oracle):
+    pi = np.array([11, 22, 33], np.uint64)
+    c = synth.arith_circuit(6, seed=4, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi))
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    assert [int(x) for x in proof[-3:]] == [11, 22, 33]
+    bad = proof.copy(); bad[-1] = 34
+    assert oc.verify(bad) != 0
+
+
+def test_reference_u32_gates(oracle):
+    """U32InterleaveGate / UninterleaveToU32Gate / UninterleaveToB32Gate bodies are the only gate code in
+    /root/reference [REF src/u32/gates/interleave_u32.rs:84-135 etc.]; a witness built from the
+    interleave definition must satisfy them and a flipped bit must not."""
+    c = synth.u32_circuit(6)
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    n_il = 3
+    w = c.wires.copy(); w[2 * n_il + 5, 2] ^= np.uint64(1)
+    rc, p2 = oc.prove(wires=w)
+    assert oc.verify(p2) != 0
+
+
+def test_fri_reduction_schedule():
+    cfg = synth.Config.standard_ecc_config()
+    assert cfg.reduction_arity_bits(20) == [4, 4, 4, 4]       # final polynomial of 16 coefficients
+    assert cfg.reduction_arity_bits(12) == [4, 4]
+    assert cfg.reduction_arity_bits(5) == []

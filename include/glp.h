@@ -107,6 +107,84 @@ GLP_API int glp_batch_merkle_proof(const glp_batch *b, uint64_t leaf_index, uint
 GLP_API size_t glp_batch_num_digests(const glp_batch *b);
 GLP_API int glp_batch_digests(const glp_batch *b, uint64_t *out);
 
+/* ---- circuits and whole proofs ------------------------------------------------------------------
+ * glp_circuit_desc carries the parts of plonky2's CommonCircuitData / ProverOnlyCircuitData /
+ * VerifierOnlyCircuitData that `prove` reads (plonk/circuit_data.rs), i.e. what
+ * `builder.build::<C>()` returns at [REF src/ecdsa/gadgets/ecdsa.rs:298].  Scope of this build:
+ * no lookup tables, zero_knowledge = false, quotient_degree_factor a power of two <= 2^rate_bits,
+ * D = 2, Poseidon hashing (PoseidonGoldilocksConfig, the `type C` of every reference driver but
+ * one [REF src/hash/keccak256.rs:281]).  Gate types a circuit may contain: see GLP_GATE_*. */
+enum {
+    GLP_GATE_NOOP = 0,             /* plonky2 gates/noop.rs */
+    GLP_GATE_CONSTANT = 1,         /* gates/constant.rs, p0 = num_consts */
+    GLP_GATE_PUBLIC_INPUT = 2,     /* gates/public_input.rs */
+    GLP_GATE_ARITHMETIC = 3,       /* gates/arithmetic_base.rs, p0 = num_ops */
+    GLP_GATE_POSEIDON = 4,         /* gates/poseidon.rs (not built yet: GLP_ERR_UNSUPPORTED) */
+    GLP_GATE_U32_INTERLEAVE = 5,   /* [REF src/u32/gates/interleave_u32.rs:33-82,84-135], p0 = num_ops */
+    GLP_GATE_UNINTERLEAVE_U32 = 6, /* [REF src/u32/gates/uninterleave_to_u32.rs:30-91,93-150], p0 = num_ops */
+    GLP_GATE_UNINTERLEAVE_B32 = 7  /* [REF src/u32/gates/uninterleave_to_b32.rs:95-150], p0 = num_ops */
+};
+
+typedef struct {
+    uint32_t type;
+    uint32_t selector_index;           /* SelectorsInfo.selector_indices[gate] */
+    uint32_t group_start, group_end;   /* SelectorsInfo.groups[selector_index] */
+    uint32_t row;                      /* index of the gate in CommonCircuitData.gates */
+    uint32_t num_constraints;
+    uint32_t p0, p1;                   /* gate parameters (see GLP_GATE_*) */
+} glp_gate;
+
+typedef struct {
+    uint32_t degree_bits;
+    uint32_t num_wires, num_routed_wires;
+    uint32_t num_constants;            /* all constant polynomials: selectors first, then gate constants */
+    uint32_t num_selectors;
+    uint32_t num_challenges;
+    uint32_t quotient_degree_factor;
+    uint32_t num_partial_products;
+    uint32_t num_gate_constraints;
+    uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    uint32_t num_reductions;
+    uint32_t reduction_arity_bits[16];
+    uint32_t num_gates;
+    uint32_t num_public_inputs;
+    const glp_gate *gates;
+    const uint64_t *k_is;              /* [num_routed_wires] */
+    uint64_t circuit_digest[4];        /* verifier_only.circuit_digest; all-zero = let the library derive it */
+    const uint64_t *constants;         /* [num_constants][n]    values on H (constant_vecs) */
+    const uint64_t *sigmas;            /* [num_routed_wires][n] values on H (sigma_vecs) */
+} glp_circuit_desc;
+
+typedef struct glp_circuit glp_circuit;
+
+/* Uploads the description and does the prover-side part of `build()`: commits constants ++ sigmas
+ * (`constants_sigmas_commitment`) and, if desc->circuit_digest is all zero, derives the digest as
+ * hash_no_pad(cap.flatten() ++ hash_pad([]) ++ [degree_bits]) (plonk/circuit_builder.rs). */
+GLP_API int glp_circuit_create(glp_ctx *ctx, const glp_circuit_desc *desc, glp_circuit **out);
+GLP_API void glp_circuit_free(glp_circuit *circuit);
+GLP_API int glp_circuit_digest(const glp_circuit *circuit, uint64_t digest_out[4]);
+GLP_API int glp_circuit_constants_sigmas_cap(const glp_circuit *circuit, uint64_t *cap_out);
+/* Number of uint64_t words of a proof of this circuit (layout below). */
+GLP_API size_t glp_proof_words(const glp_circuit *circuit);
+
+/* `CircuitData::prove` after witness generation (plonk/prover.rs `prove_with_partition_witness`,
+ * steps "compute wires commitment" .. "compute opening proofs").
+ *   wires          [num_wires][n] full witness (`witness.wire_values`), host or (…_device) HBM resident
+ *   public_inputs  [num_public_inputs]
+ *   proof_out      glp_proof_words() words, field order of plonky2's `Buffer::write_proof`:
+ *     wires_cap | plonk_zs_partial_products_cap | quotient_polys_cap           each [2^cap_height][4]
+ *     openings: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys   (ext each)
+ *     commit_phase_merkle_caps [num_reductions][2^cap_height][4]
+ *     query_round_proofs [num_query_rounds]: 4 x (leaf values, merkle path) then per reduction (evals, merkle path)
+ *     final_poly (ext coefficients) | pow_witness | public_inputs
+ * The FRI proof-of-work witness is the SMALLEST valid one (the Rust prover's rayon `find_any`
+ * returns an arbitrary valid one; every other word of the proof is a deterministic function of
+ * the inputs and of that witness). */
+GLP_API int glp_prove(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *wires, const uint64_t *public_inputs,
+                      uint64_t *proof_out);
+GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *dev_wires,
+                             const uint64_t *public_inputs, uint64_t *proof_out);
+
 #ifdef __cplusplus
 }
 #endif

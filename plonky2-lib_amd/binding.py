@@ -26,6 +26,21 @@ class GlpError(RuntimeError):
         self.code = code
 
 
+class _Gate(C.Structure):
+    _fields_ = [(f, C.c_uint32) for f in ("type", "selector_index", "group_start", "group_end", "row",
+                                          "num_constraints", "p0", "p1")]
+
+
+class _CircuitDesc(C.Structure):
+    _fields_ = ([(f, C.c_uint32) for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants",
+                                           "num_selectors", "num_challenges", "quotient_degree_factor",
+                                           "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
+                                           "proof_of_work_bits", "num_query_rounds", "num_reductions")] +
+                [("reduction_arity_bits", C.c_uint32 * 16), ("num_gates", C.c_uint32), ("num_public_inputs", C.c_uint32),
+                 ("gates", C.POINTER(_Gate)), ("k_is", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
+                 ("constants", C.c_void_p), ("sigmas", C.c_void_p)])
+
+
 def library_path():
     return _SO
 
@@ -84,10 +99,21 @@ def load_library():
         "glp_batch_merkle_proof": [vp, u64, vp],
         "glp_batch_digests": [vp, vp],
     }
+    L.glp_proof_words.restype = sz
+    L.glp_proof_words.argtypes = [vp]
+    sigs.update({
+        "glp_circuit_create": [vp, C.POINTER(_CircuitDesc), C.POINTER(vp)],
+        "glp_circuit_free": [vp],
+        "glp_circuit_digest": [vp, vp],
+        "glp_circuit_constants_sigmas_cap": [vp, vp],
+        "glp_prove": [vp, vp, vp, vp, vp],
+        "glp_prove_device": [vp, vp, vp, vp, vp],
+    })
     for name, argtypes in sigs.items():
         getattr(L, name).argtypes = argtypes
     L.glp_ctx_destroy.restype = None
     L.glp_batch_free.restype = None
+    L.glp_circuit_free.restype = None
     _lib = L
     return L
 
@@ -271,3 +297,71 @@ class Batch:
         out = np.empty((n, 4), np.uint64)
         _chk(load_library().glp_batch_digests(self._h, _p(out)))
         return out
+
+
+class Circuit:
+    """Device-resident circuit data: what `builder.build::<C>()` hands the prover
+    [REF src/ecdsa/gadgets/ecdsa.rs:298].  `desc` is an attribute bag like synth.Circuit."""
+
+    def __init__(self, ctx, desc):
+        L = load_library()
+        self.ctx, self.desc = ctx, desc
+        gates = (_Gate * len(desc.gates))()
+        for i, g in enumerate(desc.gates):
+            for f, _ in _Gate._fields_:
+                setattr(gates[i], f, int(g[f]))
+        k, const, sig = _a(desc.k_is), _a(desc.constants), _a(desc.sigmas)
+        d = _CircuitDesc()
+        for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
+                  "quotient_degree_factor", "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
+                  "proof_of_work_bits", "num_query_rounds"):
+            setattr(d, f, int(getattr(desc, f)))
+        d.num_reductions = len(desc.reduction_arity_bits)
+        for i, ab in enumerate(desc.reduction_arity_bits):
+            d.reduction_arity_bits[i] = int(ab)
+        d.num_gates, d.num_public_inputs = len(desc.gates), int(len(desc.public_inputs))
+        d.gates = C.cast(gates, C.POINTER(_Gate))
+        d.k_is, d.constants, d.sigmas = k.ctypes.data, const.ctypes.data, sig.ctypes.data
+        dig = getattr(desc, "circuit_digest", None)
+        if dig is not None:
+            for i in range(4):
+                d.circuit_digest[i] = int(dig[i])
+        self._h = C.c_void_p()
+        _chk(L.glp_circuit_create(ctx._h, C.byref(d), C.byref(self._h)))
+        self.proof_words = L.glp_proof_words(self._h)
+
+    def free(self):
+        if getattr(self, "_h", None):
+            load_library().glp_circuit_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def digest(self):
+        out = np.empty(4, np.uint64)
+        _chk(load_library().glp_circuit_digest(self._h, _p(out)))
+        return out
+
+    def constants_sigmas_cap(self):
+        out = np.empty((1 << self.desc.cap_height, 4), np.uint64)
+        _chk(load_library().glp_circuit_constants_sigmas_cap(self._h, _p(out)))
+        return out
+
+    def prove(self, wires=None, public_inputs=None):
+        """`data.prove(pw)` after witness generation: full witness in, proof words out (include/glp.h)."""
+        w = _a(self.desc.wires if wires is None else wires)
+        pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)
+        proof = np.zeros(self.proof_words, np.uint64)
+        _chk(load_library().glp_prove(self.ctx._h, self._h, _p(w), _p(pi) if pi.size else None, _p(proof)))
+        return proof
+
+    def prove_device(self, dev_wires_ptr, public_inputs=None):
+        pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)
+        proof = np.zeros(self.proof_words, np.uint64)
+        _chk(load_library().glp_prove_device(self.ctx._h, self._h, C.c_void_p(dev_wires_ptr), _p(pi) if pi.size else None,
+                                             _p(proof)))
+        return proof

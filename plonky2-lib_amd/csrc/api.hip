@@ -274,7 +274,7 @@ void batch_destroy(glp_batch *b) {
 }
 
 // dev_in: values (natural) if from_values, else coefficients in natural order.
-int batch_build(glp_ctx *c, const u64 *dev_in, bool from_values, u32 ncols, int lg, int rate_bits, int cap_height,
+int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg, int rate_bits, int cap_height,
                 glp_batch **out) {
     GLP_REQUIRE(out, "out is null");
     *out = nullptr;
@@ -290,12 +290,15 @@ int batch_build(glp_ctx *c, const u64 *dev_in, bool from_values, u32 ncols, int 
     GLP_TRY(c->alloc((void **)&b->coeffs, (size_t)ncols * n * 8));
     GLP_TRY(c->alloc((void **)&b->lde, (size_t)ncols * N * 8));
     GLP_TRY(c->alloc((void **)&b->digests, b->ndigests * 32));
-    if (from_values) {
+    if (input_kind == BATCH_VALUES) {
         StageScope st(c, "intt", 16.0 * n * ncols);
         GLP_TRY(intt_values_to_coeffs(c, dev_in, b->coeffs, ncols, lg));
-    } else {
+    } else if (input_kind == BATCH_COEFFS_NATURAL) {
         StageScope st(c, "bitrev_coeffs", 16.0 * n * ncols);
         GLP_TRY(bitrev_copy(c, dev_in, b->coeffs, ncols, lg));
+    } else {
+        StageScope st(c, "copy_coeffs", 16.0 * n * ncols);
+        GLP_HIP(hipMemcpyAsync(b->coeffs, dev_in, (size_t)ncols * n * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     {
         StageScope st(c, "lde", (8.0 * n + 8.0 * N) * ncols);
@@ -317,7 +320,7 @@ static int batch_from_host(glp_ctx *c, const u64 *host, bool from_values, u32 nc
     int rc = GLP_OK;
     hipError_t e = hipMemcpyAsync(d, host, tot * 8, hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
-    if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, from_values, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+    if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, from_values ? BATCH_VALUES : BATCH_COEFFS_NATURAL, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
     (void)hipStreamSynchronize(c->stream);
     c->release(d);
     return rc;
@@ -339,13 +342,13 @@ int glp_batch_from_values_device(glp_ctx *c, const uint64_t *dev_values, uint32_
                                  uint32_t cap_height, glp_batch **out) {
     GLP_REQUIRE(c && dev_values && out, "null argument");
     GLP_TRY(bind(c));
-    return batch_build(c, dev_values, true, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+    return batch_build(c, dev_values, BATCH_VALUES, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
 }
 int glp_batch_from_coeffs_device(glp_ctx *c, const uint64_t *dev_coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
                                  uint32_t cap_height, glp_batch **out) {
     GLP_REQUIRE(c && dev_coeffs && out, "null argument");
     GLP_TRY(bind(c));
-    return batch_build(c, dev_coeffs, false, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+    return batch_build(c, dev_coeffs, BATCH_COEFFS_NATURAL, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
 }
 void glp_batch_free(glp_batch *b) { batch_destroy(b); }
 

@@ -13,7 +13,8 @@ struct glp_batch {
 };
 
 namespace glp {
-int batch_build(glp_ctx *c, const u64 *dev_in, bool from_values, u32 ncols, int lg, int rate_bits, int cap_height,
+enum BatchInput { BATCH_VALUES = 0, BATCH_COEFFS_NATURAL = 1, BATCH_COEFFS_BITREV = 2 };
+int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg, int rate_bits, int cap_height,
                 glp_batch **out);
 void batch_destroy(glp_batch *b);
 }  // namespace glp

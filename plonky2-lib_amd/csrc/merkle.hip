@@ -126,6 +126,8 @@ static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_he
     return GLP_OK;
 }
 
+int merkle_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height) { return build_levels(c, dev_digests, nleaves, cap_height); }
+
 int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, int cap_height, u64 *dev_digests) {
     const size_t N = (size_t)1 << (lg + rate_bits);
     if (cap_height < 0 || ((size_t)1 << cap_height) > N)

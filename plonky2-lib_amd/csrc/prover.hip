@@ -1,0 +1,996 @@
+// prover.hip -- `CircuitData::prove` after witness generation, on one MI355X.
+//
+// Replaces plonky2 0.1.4 `plonk/prover.rs::prove_with_partition_witness` (from "compute wires
+// commitment" on), `plonk/vanishing_poly.rs`, `plonk/proof.rs::OpeningSet::new`,
+// `fri/oracle.rs::prove_openings`, `fri/prover.rs::{fri_committed_trees, fri_proof_of_work,
+// fri_prover_query_rounds}` and `iop/challenger.rs`, i.e. everything behind `data.prove(pw)`
+// [REF src/ecdsa/gadgets/ecdsa.rs:349] except witness generation (CPU, the reference's generators).
+// Gate bodies: plonky2 gates/{noop,constant,public_input,arithmetic_base}.rs and the reference's
+// [REF src/u32/gates/interleave_u32.rs:84-135, uninterleave_to_u32.rs:93-150, uninterleave_to_b32.rs:95-150].
+//
+// Data stays on the GPU between stages; the host runs the Fiat-Shamir transcript (a few dozen
+// Poseidon permutations) and sequences kernels.  Per proof the PCIe traffic is caps, openings,
+// query paths (KBs) in and challenges out.
+#include <algorithm>
+#include <string.h>
+#include "batch.h"
+#include "common.h"
+#include "merkle.h"
+#include "ntt.h"
+#include "poseidon.h"
+
+using namespace glp;
+using namespace glf;
+
+constexpr int MAXCH = 4;      // num_challenges supported
+constexpr int MAXR = 16;      // 2^rate_bits supported
+
+struct DevGate { u32 type, selector_index, group_start, group_end, row, num_constraints, p0, p1; };
+
+struct Layout {
+    size_t caps, openings, fri_caps, queries, final_poly, pow, pis, total, nopen, query_stride;
+    u32 oracle_cols[4], depth0, step_depth[16], final_len;
+};
+
+struct glp_circuit {
+    glp_ctx *ctx = nullptr;
+    glp_circuit_desc d;            // scalars + host copies below
+    std::vector<glp_gate> gates;
+    std::vector<u64> k_is;
+    u64 digest[4];
+    DevGate *dev_gates = nullptr;
+    u64 *dev_k_is = nullptr;
+    u64 *dev_sigmas = nullptr;     // [nr][n] values on H (natural order), for the partial products
+    glp_batch *cs = nullptr;       // constants_sigmas_commitment
+    std::vector<u64> cs_cap;
+    Layout L;
+};
+
+// ------------------------------------------------------------------------------------------ transcript
+namespace {
+struct Challenger {   // iop/challenger.rs, overwrite-mode duplex sponge; challenges pop from the END of the rate
+    u64 st[12]; u64 in[8]; int nin = 0; u64 out[8]; int nout = 0;
+    Challenger() { memset(st, 0, sizeof(st)); }
+    void duplex() {
+        for (int i = 0; i < nin; i++) st[i] = in[i];
+        nin = 0;
+        pos::permute(st);
+        memcpy(out, st, 64); nout = 8;
+    }
+    void observe(const u64 *e, size_t n) {
+        for (size_t i = 0; i < n; i++) { nout = 0; in[nin++] = e[i]; if (nin == 8) duplex(); }
+    }
+    u64 get() { if (nin > 0 || nout == 0) duplex(); return out[--nout]; }
+    ext2 get_ext() { u64 a = get(); u64 b = get(); return e_make(a, b); }
+};
+void host_hash_no_pad(const u64 *in, size_t len, u64 out[4]) {
+    u64 st[12] = {0};
+    for (size_t off = 0; off < len; off += 8) {
+        size_t c = std::min<size_t>(8, len - off);
+        for (size_t i = 0; i < c; i++) st[i] = in[off + i];
+        pos::permute(st);
+    }
+    memcpy(out, st, 32);
+}
+void make_layout(const glp_circuit_desc &c, Layout &L) {
+    const u32 cap = 1u << c.cap_height, nch = c.num_challenges;
+    memset(&L, 0, sizeof(L));
+    L.oracle_cols[0] = c.num_constants + c.num_routed_wires;
+    L.oracle_cols[1] = c.num_wires;
+    L.oracle_cols[2] = nch * (1 + c.num_partial_products);
+    L.oracle_cols[3] = nch * c.quotient_degree_factor;
+    L.nopen = (size_t)c.num_constants + c.num_routed_wires + c.num_wires + 2 * nch + nch * c.num_partial_products +
+              nch * c.quotient_degree_factor;
+    L.openings = 3 * (size_t)cap * 4;
+    L.fri_caps = L.openings + 2 * L.nopen;
+    L.queries = L.fri_caps + (size_t)c.num_reductions * cap * 4;
+    const u32 lgN = c.degree_bits + c.rate_bits;
+    L.depth0 = lgN - c.cap_height;
+    size_t q = 0;
+    for (int k = 0; k < 4; k++) q += L.oracle_cols[k] + 4 * (size_t)L.depth0;
+    u32 lg = lgN;
+    for (u32 i = 0; i < c.num_reductions; i++) {
+        const u32 ab = c.reduction_arity_bits[i];
+        lg -= ab;
+        L.step_depth[i] = lg - c.cap_height;
+        q += 2 * ((size_t)1 << ab) + 4 * (size_t)L.step_depth[i];
+    }
+    L.query_stride = q;
+    L.final_len = 1u << (lg - c.rate_bits);
+    L.final_poly = L.queries + q * c.num_query_rounds;
+    L.pow = L.final_poly + 2 * (size_t)L.final_len;
+    L.pis = L.pow + 1;
+    L.total = L.pis + c.num_public_inputs;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ kernels
+__device__ __forceinline__ u64 dpow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = mul(r, b); b = sqr(b); e >>= 1; }
+    return r;
+}
+
+struct PPArgs {
+    const u64 *wires, *sigmas, *k_is;
+    u64 *zp;
+    u64 betas[MAXCH], gammas[MAXCH];
+    u64 w_n;
+    u32 lg, nr, nch, npp, qdf;
+};
+// K5a: per row, the running products of the quotient chunks  prod_{j in chunk} (w_j + beta k_j x + gamma)/(w_j + beta sigma_j + gamma)
+__global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
+    const size_t n = (size_t)1 << a.lg;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 x = dpow(a.w_n, i);
+    u64 cum[MAXCH];
+    for (u32 c = 0; c < a.nch; c++) cum[c] = 1;
+    for (u32 chunk = 0; chunk <= a.npp; chunk++) {
+        u64 num[MAXCH], den[MAXCH];
+        for (u32 c = 0; c < a.nch; c++) { num[c] = 1; den[c] = 1; }
+        const u32 j1 = min((chunk + 1) * a.qdf, a.nr);
+        for (u32 j = chunk * a.qdf; j < j1; j++) {
+            const u64 w = a.wires[(size_t)j * n + i], s = a.sigmas[(size_t)j * n + i];
+            const u64 kx = mul(a.k_is[j], x);
+            for (u32 c = 0; c < a.nch; c++) {
+                num[c] = mul(num[c], add(add(w, mul(a.betas[c], kx)), a.gammas[c]));
+                den[c] = mul(den[c], add(add(w, mul(a.betas[c], s)), a.gammas[c]));
+            }
+        }
+        for (u32 c = 0; c < a.nch; c++) {
+            cum[c] = mul(cum[c], mul(num[c], inv(den[c])));
+            const u32 col = chunk < a.npp ? a.nch + c * a.npp + chunk : c;   // Z column holds the row product for now
+            a.zp[(size_t)col * n + i] = cum[c];
+        }
+    }
+}
+// K5b: product of each block of 256 row products
+__global__ __launch_bounds__(256) void k_pp_block_tot(const u64 *zp, u64 *tot, u32 lg, u32 nblocks) {
+    __shared__ u64 sh[256];
+    const size_t n = (size_t)1 << lg;
+    const u32 c = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const size_t i = (size_t)b * 256 + t;
+    sh[t] = i < n ? zp[(size_t)c * n + i] : 1;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) sh[t] = mul(sh[t], sh[t + s]); __syncthreads(); }
+    if (t == 0) tot[(size_t)c * nblocks + b] = sh[0];
+}
+// K5c: exclusive prefix product of the block totals (one workgroup per challenge)
+__global__ __launch_bounds__(256) void k_pp_scan_tot(u64 *tot, u32 nblocks) {
+    __shared__ u64 sh[256];
+    const u32 c = blockIdx.x, t = threadIdx.x;
+    u64 *v = tot + (size_t)c * nblocks;
+    const u32 m = (nblocks + 255) / 256;
+    u64 loc = 1;
+    for (u32 k = t * m; k < min((t + 1) * m, nblocks); k++) loc = mul(loc, v[k]);
+    sh[t] = loc;
+    __syncthreads();
+    if (t == 0) { u64 acc = 1; for (int k = 0; k < 256; k++) { u64 x = sh[k]; sh[k] = acc; acc = mul(acc, x); } }
+    __syncthreads();
+    u64 acc = sh[t];
+    for (u32 k = t * m; k < min((t + 1) * m, nblocks); k++) { u64 x = v[k]; v[k] = acc; acc = mul(acc, x); }
+}
+// K5d: Z(x_i) = prefix(block) * in-block exclusive scan; partial products *= Z
+__global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 lg, u32 nblocks, u32 nch, u32 npp) {
+    __shared__ u64 sh[2][256];
+    const size_t n = (size_t)1 << lg;
+    const u32 c = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+    const size_t i = (size_t)b * 256 + t;
+    const u64 mine = i < n ? zp[(size_t)c * n + i] : 1;
+    int cur = 0;
+    sh[0][t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {     // Hillis-Steele inclusive scan
+        u64 v = sh[cur][t];
+        if (t >= off) v = mul(sh[cur][t - off], v);
+        sh[cur ^ 1][t] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const u64 excl = t ? sh[cur][t - 1] : 1;
+    if (i >= n) return;
+    const u64 z = mul(tot[(size_t)c * nblocks + b], excl);
+    zp[(size_t)c * n + i] = z;
+    for (u32 k = 0; k < npp; k++) {
+        const size_t o = (size_t)(nch + c * npp + k) * n + i;
+        zp[o] = mul(zp[o], z);
+    }
+}
+
+struct QArgs {
+    const u64 *cs, *wl, *zl;        // coset-major LDEs [ncols][R][n]
+    u64 *out;                       // [nch][Rq][n]
+    const DevGate *gates;
+    const u64 *k_is, *apow;         // apow [nch][nterms]
+    u64 betas[MAXCH], gammas[MAXCH], pih[4];
+    u64 shift_r[MAXR], zh[MAXR], zh_inv[MAXR];   // per evaluated plane
+    u64 w_n, n_field;
+    u32 lg, rb, step, nc, nsel, nr, nw, nch, npp, qdf, num_gates, nterms, many_selectors;
+};
+// K6: vanishing polynomial / Z_H on the planes r = 0, step, 2 step, ... of the coset-major LDE domain.
+//   terms: [L_0 (Z_c - 1)]_c, [prev*num - next*den]_{c,chunk}, gate constraints; res_c = sum_k term_k alpha_c^k
+__global__ __launch_bounds__(256) void k_quotient(QArgs a) {
+    const size_t n = (size_t)1 << a.lg, N = n << a.rb;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u32 rq = blockIdx.y, r = rq * a.step;
+    const size_t slot = (size_t)r * n + q, slot_next = (size_t)r * n + ((q + 1) & (n - 1));
+    const u64 x = mul(a.shift_r[rq], dpow(a.w_n, q));
+    const u32 nch = a.nch, nchunks = a.npp + 1, nt = a.nterms;
+    u64 acc[MAXCH], zx[MAXCH], zg[MAXCH];
+    for (u32 c = 0; c < nch; c++) { acc[c] = 0; zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
+    const u64 l0 = mul(a.zh[rq], inv(mul(a.n_field, sub(x, 1))));
+    for (u32 c = 0; c < nch; c++) {
+        const u64 t = mul(l0, sub(zx[c], 1));
+        for (u32 c2 = 0; c2 < nch; c2++) acc[c2] = add(acc[c2], mul(t, a.apow[c2 * nt + c]));
+    }
+    for (u32 chunk = 0; chunk < nchunks; chunk++) {
+        u64 num[MAXCH], den[MAXCH];
+        for (u32 c = 0; c < nch; c++) { num[c] = 1; den[c] = 1; }
+        const u32 j1 = min((chunk + 1) * a.qdf, a.nr);
+        for (u32 j = chunk * a.qdf; j < j1; j++) {
+            const u64 w = a.wl[(size_t)j * N + slot], s = a.cs[(size_t)(a.nc + j) * N + slot];
+            const u64 kx = mul(a.k_is[j], x);
+            for (u32 c = 0; c < nch; c++) {
+                num[c] = mul(num[c], add(add(w, mul(a.betas[c], kx)), a.gammas[c]));
+                den[c] = mul(den[c], add(add(w, mul(a.betas[c], s)), a.gammas[c]));
+            }
+        }
+        for (u32 c = 0; c < nch; c++) {
+            const u64 prev = chunk == 0 ? zx[c] : a.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
+            const u64 next = chunk == nchunks - 1 ? zg[c] : a.zl[(size_t)(nch + c * a.npp + chunk) * N + slot];
+            const u64 t = sub(mul(prev, num[c]), mul(next, den[c]));
+            const u32 k = nch + c * nchunks + chunk;
+            for (u32 c2 = 0; c2 < nch; c2++) acc[c2] = add(acc[c2], mul(t, a.apow[c2 * nt + k]));
+        }
+    }
+    const u32 k0 = nch + nch * nchunks;
+    const u64 *W = a.wl + slot;                       // wire j  -> W[j * N]
+    const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
+    for (u32 gi = 0; gi < a.num_gates; gi++) {
+        const DevGate g = a.gates[gi];
+        const u64 s = a.cs[(size_t)g.selector_index * N + slot];
+        u64 filter = 1;
+        for (u32 i = g.group_start; i < g.group_end; i++)
+            if (i != g.row) filter = mul(filter, sub((u64)i, s));
+        if (a.many_selectors) filter = mul(filter, sub(0xFFFFFFFFull, s));
+        u64 ga[MAXCH];
+        for (u32 c = 0; c < nch; c++) ga[c] = 0;
+        const u64 *ap = a.apow + k0;
+#define EMIT(k, v)                                                                     \
+    do {                                                                               \
+        const u64 _v = (v);                                                            \
+        for (u32 c2 = 0; c2 < nch; c2++) ga[c2] = add(ga[c2], mul(_v, ap[c2 * nt + (k)])); \
+    } while (0)
+        switch (g.type) {
+        case GLP_GATE_CONSTANT:
+            for (u32 i = 0; i < g.p0; i++) EMIT(i, sub(GC[(size_t)i * N], W[(size_t)i * N]));
+            break;
+        case GLP_GATE_PUBLIC_INPUT:
+            for (u32 i = 0; i < 4; i++) EMIT(i, sub(W[(size_t)i * N], a.pih[i]));
+            break;
+        case GLP_GATE_ARITHMETIC: {
+            const u64 c0 = GC[0], c1 = GC[N];
+            for (u32 i = 0; i < g.p0; i++) {
+                const u64 m0 = W[(size_t)(4 * i) * N], m1 = W[(size_t)(4 * i + 1) * N];
+                const u64 ad = W[(size_t)(4 * i + 2) * N], o = W[(size_t)(4 * i + 3) * N];
+                EMIT(i, sub(o, add(mul(mul(m0, m1), c0), mul(ad, c1))));
+            }
+            break;
+        }
+        case GLP_GATE_U32_INTERLEAVE: {
+            u32 k = 0;
+            for (u32 i = 0; i < g.p0; i++) {
+                const u64 xw = W[(size_t)(2 * i) * N], xi = W[(size_t)(2 * i + 1) * N];
+                const u64 *bits = W + (size_t)(2 * g.p0 + 32 * i) * N;
+                u64 cx = 0, cxi = 0;
+                const u32 kb = k + 2;
+                for (u32 b = 0; b < 32; b++) {
+                    const u64 bit = bits[(size_t)b * N];
+                    cx = add(dbl(cx), bit);
+                    cxi = add(dbl(dbl(cxi)), bit);
+                    EMIT(kb + b, mul(bit, sub(bit, 1)));
+                }
+                EMIT(k, sub(cx, xw));
+                EMIT(k + 1, sub(cxi, xi));
+                k += 34;
+            }
+            break;
+        }
+        case GLP_GATE_UNINTERLEAVE_U32:
+        case GLP_GATE_UNINTERLEAVE_B32: {
+            u32 k = 0;
+            for (u32 i = 0; i < g.p0; i++) {
+                const u64 xi = W[(size_t)(3 * i) * N], xe = W[(size_t)(3 * i + 1) * N], xo = W[(size_t)(3 * i + 2) * N];
+                const u64 *bits = W + (size_t)(3 * g.p0 + 64 * i) * N;
+                u64 cxi = 0, ce = 0, co = 0;
+                const u32 kb = k + 3;
+                for (u32 j = 0; j < 32; j++) {   // Horner from the most significant bit: coeff 2^(31-j) or 4^(31-j)
+                    const u64 be = bits[(size_t)(2 * j) * N], bo = bits[(size_t)(2 * j + 1) * N];
+                    cxi = add(dbl(add(dbl(cxi), be)), bo);
+                    if (g.type == GLP_GATE_UNINTERLEAVE_U32) { ce = add(dbl(ce), be); co = add(dbl(co), bo); }
+                    else { ce = add(dbl(dbl(ce)), be); co = add(dbl(dbl(co)), bo); }
+                    EMIT(kb + 2 * j, mul(be, sub(be, 1)));
+                    EMIT(kb + 2 * j + 1, mul(bo, sub(bo, 1)));
+                }
+                EMIT(k, sub(cxi, xi));
+                EMIT(k + 1, sub(ce, xe));
+                EMIT(k + 2, sub(co, xo));
+                k += 67;
+            }
+            break;
+        }
+        default: break;   // NOOP
+        }
+#undef EMIT
+        for (u32 c = 0; c < nch; c++) acc[c] = add(acc[c], mul(filter, ga[c]));
+    }
+    const size_t Rq = (size_t)gridDim.y;
+    for (u32 c = 0; c < nch; c++) a.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
+}
+
+// K6b: after the per-plane inverse NTT: undo the plane twist, inverse DFT across planes, undo the coset shift.
+//   V [nch][Rq][n] (bit-reversed k')  ->  chunk coefficients [nch*Rq][n] (bit-reversed), chunk c = X^(c n) block
+struct QCArgs { const u64 *V; u64 *out; u64 wM_inv, wR_inv, g_inv, rq_inv; u64 gn_inv_pow[MAXR]; u32 lg, Rq; };
+__global__ __launch_bounds__(256) void k_quotient_combine(QCArgs a) {
+    const size_t n = (size_t)1 << a.lg;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const u32 ch = blockIdx.y, Rq = a.Rq;
+    const u32 kp = bitrev32((u32)p, a.lg);
+    const u64 tw = dpow(a.wM_inv, kp);            // w_M^-k'
+    const u64 gk = mul(dpow(a.g_inv, kp), a.rq_inv);
+    u64 y[MAXR];
+    u64 t = 1;
+    for (u32 r = 0; r < Rq; r++) { y[r] = mul(a.V[((size_t)ch * Rq + r) * n + p], t); t = mul(t, tw); }
+    u64 wc = 1;                                    // w_Rq^-c
+    for (u32 c = 0; c < Rq; c++) {
+        u64 s = 0, w = 1;
+        for (u32 r = 0; r < Rq; r++) { s = add(s, mul(y[r], w)); w = mul(w, wc); }
+        a.out[((size_t)ch * Rq + c) * n + p] = mul(s, mul(gk, a.gn_inv_pow[c]));
+        wc = mul(wc, a.wR_inv);
+    }
+}
+
+// zt[p] = z^bitrev(p)  (extension), from z^(2^b), b < lg
+struct ZTArgs { u64 *zt; ext2 zp2[24]; u32 lg; };
+__global__ __launch_bounds__(256) void k_zeta_table(ZTArgs a) {
+    const size_t n = (size_t)1 << a.lg;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const u32 k = bitrev32((u32)p, a.lg);
+    ext2 acc = e_from(1);
+    for (u32 b = 0; b < a.lg; b++) if ((k >> b) & 1) acc = e_mul(acc, a.zp2[b]);
+    a.zt[2 * p] = acc.a; a.zt[2 * p + 1] = acc.b;
+}
+// K7: partial sums of  sum_p coeffs[col][p] * zt[p]   grid = (OPEN_BLOCKS, ncols)
+constexpr int OPEN_BLOCKS = 32;
+__global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *zt, u64 *partial, u32 lg) {
+    __shared__ u64 sa[256], sb[256];
+    const size_t n = (size_t)1 << lg;
+    const u32 col = blockIdx.y, t = threadIdx.x;
+    u64 a = 0, b = 0;
+    for (size_t p = (size_t)blockIdx.x * 256 + t; p < n; p += (size_t)OPEN_BLOCKS * 256) {
+        const u64 c = coeffs[(size_t)col * n + p];
+        a = add(a, mul(c, zt[2 * p]));
+        b = add(b, mul(c, zt[2 * p + 1]));
+    }
+    sa[t] = a; sb[t] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (t < s) { sa[t] = add(sa[t], sa[t + s]); sb[t] = add(sb[t], sb[t + s]); } __syncthreads(); }
+    if (t == 0) { partial[2 * ((size_t)col * OPEN_BLOCKS + blockIdx.x)] = sa[0]; partial[2 * ((size_t)col * OPEN_BLOCKS + blockIdx.x) + 1] = sb[0]; }
+}
+
+// K8: values of the FRI batch polynomial on the coset plane 0 (x_q = g w_n^q):
+//   F(x) = alpha^nch * (sum_j alpha^j f_j(x) - red0)/(x - zeta) + (sum_{j<nch} alpha^j Z_j(x) - red1)/(x - g zeta)
+struct FVArgs {
+    const u64 *lde[4]; u32 ncols[4];
+    const u64 *apow;            // ext alpha^j, j < total columns
+    u64 *out;                   // [2][n]
+    ext2 red0, red1, zeta, zeta_next, shift_acc;   // shift_acc = alpha^nch
+    u64 w_n, g;
+    u32 lg, rb, nch;
+};
+__global__ __launch_bounds__(256) void k_final_values(FVArgs a) {
+    const size_t n = (size_t)1 << a.lg, N = n << a.rb;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    ext2 acc0 = e_from(0), acc1 = e_from(0);
+    u32 j = 0;
+    for (int k = 0; k < 4; k++) {
+        const u64 *l = a.lde[k] + q;
+        for (u32 c = 0; c < a.ncols[k]; c++, j++) {
+            const u64 v = l[(size_t)c * N];
+            const ext2 ap = e_make(a.apow[2 * j], a.apow[2 * j + 1]);
+            acc0 = e_add(acc0, e_scale(ap, v));
+            if (k == 2 && c < a.nch) {
+                const ext2 ap1 = e_make(a.apow[2 * c], a.apow[2 * c + 1]);
+                acc1 = e_add(acc1, e_scale(ap1, v));
+            }
+        }
+    }
+    const u64 x = mul(a.g, dpow(a.w_n, q));
+    const ext2 d0 = e_inv(e_sub(e_from(x), a.zeta)), d1 = e_inv(e_sub(e_from(x), a.zeta_next));
+    ext2 f = e_mul(e_mul(e_sub(acc0, a.red0), d0), a.shift_acc);
+    f = e_add(f, e_mul(e_sub(acc1, a.red1), d1));
+    a.out[q] = f.a; a.out[n + q] = f.b;
+}
+// data[c][p] *= base^bitrev(p)
+__global__ __launch_bounds__(256) void k_scale_bitrev_pow(u64 *data, u64 base, u32 lg) {
+    const size_t n = (size_t)1 << lg;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const u64 f = dpow(base, bitrev32((u32)p, lg));
+    data[(size_t)blockIdx.y * n + p] = mul(data[(size_t)blockIdx.y * n + p], f);
+}
+
+// K9a: FRI commit-phase leaves.  vals = coset-major LDE [2][R][ncur] of the current polynomial (L = R*ncur
+// points); leaf m = the `arity` extension values at natural indices bitrev_L(m*arity + t).  Lane = M' = bitrev(m).
+__global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab) {
+    const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
+    const size_t Mp = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (Mp >= nleaves) return;
+    const size_t m = bitrev32((u32)Mp, lgL - ab);
+    const u32 arity = 1u << ab;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = 0;
+    const u64 *re = vals, *im = vals + L;
+    u32 fill = 0;
+    for (u32 t = 0; t < arity; t++) {
+        const size_t i = (size_t)bitrev32(t, ab) * nleaves + Mp;
+        const size_t pos = (i & (((size_t)1 << rb) - 1)) * ncur + (i >> rb);
+        s[fill++] = re[pos];
+        s[fill++] = im[pos];
+        if (fill == 8) { if (2 * arity > 4) pos::permute(s); fill = 0; }
+    }
+    if (fill && 2 * arity > 4) pos::permute(s);
+    ulonglong2 d0, d1;
+    d0.x = s[0]; d0.y = s[1]; d1.x = s[2]; d1.y = s[3];
+    reinterpret_cast<ulonglong2 *>(digests + 4 * m)[0] = d0;
+    reinterpret_cast<ulonglong2 *>(digests + 4 * m)[1] = d1;
+}
+// K9b: fold coefficients (bit-reversed layout): new[p'] = sum_t beta^t old[bitrev(t) * nnew + p']
+__global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ext2 beta, u32 lg_old, u32 ab) {
+    const size_t nold = (size_t)1 << lg_old, nnew = nold >> ab;
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nnew) return;
+    ext2 acc = e_from(0);
+    for (u32 t = 1u << ab; t-- > 0;) {
+        const size_t o = (size_t)bitrev32(t, ab) * nnew + p;
+        acc = e_add(e_mul(acc, beta), e_make(oldc[o], oldc[nold + o]));
+    }
+    newc[p] = acc.a; newc[nnew + p] = acc.b;
+}
+// leaf evals for the query phase: out[k][2*t..] = the arity values of leaf idx[k]
+__global__ void k_fri_gather_leaf(const u64 *vals, u32 lgL, u32 rb, u32 ab, const u64 *idx, u32 count, u64 *out) {
+    const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
+    const u32 arity = 1u << ab;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)count * arity) return;
+    const u32 k = (u32)(gid / arity), t = (u32)(gid % arity);
+    const size_t m = idx[k];
+    const size_t Mp = bitrev32((u32)m, lgL - ab);
+    const size_t i = (size_t)bitrev32(t, ab) * nleaves + Mp;
+    const size_t pos = (i & (((size_t)1 << rb) - 1)) * ncur + (i >> rb);
+    out[((size_t)k * arity + t) * 2] = vals[pos];
+    out[((size_t)k * arity + t) * 2 + 1] = vals[L + pos];
+}
+
+// K10: proof-of-work grinding; smallest candidate in [base, base + count) whose response has `bits` leading zeros
+struct PowArgs { u64 st[12]; u32 pos, bits; u64 base; unsigned long long *best; };
+__global__ __launch_bounds__(256) void k_pow(PowArgs a) {
+    const u64 cand = a.base + (u64)blockIdx.x * 256 + threadIdx.x;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = a.st[i];
+    s[a.pos] = cand;        // candidates stay far below p
+    pos::permute(s);
+    if (a.bits == 0 || (s[7] >> (64 - a.bits)) == 0) atomicMin(a.best, (unsigned long long)cand);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+namespace {
+struct Tmp {   // pool-backed scratch for one prove() call
+    glp_ctx *c;
+    std::vector<void *> ptrs;
+    explicit Tmp(glp_ctx *ctx) : c(ctx) {}
+    ~Tmp() { (void)hipStreamSynchronize(c->stream); for (void *p : ptrs) c->release(p); }
+    int get(u64 **p, size_t elems) {
+        void *v = nullptr;
+        int rc = c->alloc(&v, elems * sizeof(u64));
+        if (rc == GLP_OK) { ptrs.push_back(v); *p = (u64 *)v; }
+        return rc;
+    }
+};
+struct BatchHolder {
+    glp_batch *b = nullptr;
+    ~BatchHolder() { batch_destroy(b); }
+};
+inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+int d2h(glp_ctx *c, void *dst, const void *src, size_t bytes) {
+    GLP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+int h2d(glp_ctx *c, void *dst, const void *src, size_t bytes) {
+    GLP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));   // the source is usually a stack/vector temporary
+    return GLP_OK;
+}
+int batch_cap_host(glp_ctx *c, const glp_batch *b, std::vector<u64> &cap) {
+    const size_t N = (size_t)1 << (b->lg + b->rate_bits);
+    cap.resize((size_t)4 << b->cap_height);
+    return d2h(c, cap.data(), b->digests + 4 * merkle_cap_offset(N, b->cap_height), cap.size() * 8);
+}
+// evaluate every polynomial of a batch at z: out[col] (ext)
+int open_batch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial, std::vector<ext2> &out) {
+    dim3 g(OPEN_BLOCKS, b->ncols);
+    hipLaunchKernelGGL(k_open_dot, g, dim3(256), 0, c->stream, b->coeffs, dev_zt, dev_partial, (u32)b->lg);
+    GLP_HIP(hipGetLastError());
+    std::vector<u64> h((size_t)b->ncols * OPEN_BLOCKS * 2);
+    GLP_TRY(d2h(c, h.data(), dev_partial, h.size() * 8));
+    out.resize(b->ncols);
+    for (u32 col = 0; col < b->ncols; col++) {
+        u64 a = 0, bb = 0;
+        for (int k = 0; k < OPEN_BLOCKS; k++) { a = add(a, h[2 * ((size_t)col * OPEN_BLOCKS + k)]); bb = add(bb, h[2 * ((size_t)col * OPEN_BLOCKS + k) + 1]); }
+        out[col] = e_make(a, bb);
+    }
+    return GLP_OK;
+}
+int zeta_table(glp_ctx *c, ext2 z, int lg, u64 *dev_zt) {
+    ZTArgs za;
+    za.zt = dev_zt; za.lg = (u32)lg;
+    ext2 p = z;
+    for (int b = 0; b < 24; b++) { za.zp2[b] = p; p = e_sqr(p); }
+    hipLaunchKernelGGL(k_zeta_table, dim3(nblk((size_t)1 << lg)), dim3(256), 0, c->stream, za);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+}  // namespace
+
+static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, const u64 *public_inputs, u64 *proof) {
+    const glp_circuit_desc &d = cc->d;
+    const Layout &L = cc->L;
+    const int lg = (int)d.degree_bits, rb = (int)d.rate_bits;
+    const size_t n = (size_t)1 << lg, N = n << rb;
+    const u32 nch = d.num_challenges, nr = d.num_routed_wires, nw = d.num_wires, nc = d.num_constants;
+    const u32 qdf = d.quotient_degree_factor, npp = d.num_partial_products, capn = 1u << d.cap_height;
+    const u32 nzp = nch * (1 + npp);
+    memset(proof, 0, L.total * 8);
+    Tmp tmp(c);
+
+    u64 pih[4];
+    host_hash_no_pad(public_inputs, d.num_public_inputs, pih);
+    if (d.num_public_inputs) memcpy(proof + L.pis, public_inputs, (size_t)d.num_public_inputs * 8);
+
+    // ---- wires commitment
+    BatchHolder wb;
+    GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b));
+    std::vector<u64> cap;
+    GLP_TRY(batch_cap_host(c, wb.b, cap));
+    memcpy(proof + L.caps, cap.data(), capn * 32);
+
+    Challenger ch;
+    ch.observe(cc->digest, 4);
+    ch.observe(pih, 4);
+    ch.observe(cap.data(), capn * 4);
+    u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
+    for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
+    for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
+
+    // ---- partial products and Z
+    BatchHolder zb;
+    {
+        u64 *zp, *tot;
+        const u32 nblocks = nblk(n);
+        GLP_TRY(tmp.get(&zp, (size_t)nzp * n));
+        GLP_TRY(tmp.get(&tot, (size_t)nch * nblocks));
+        {
+            StageScope st(c, "partial_products", 8.0 * n * (2.0 * nr + nzp));
+            PPArgs a;
+            a.wires = dev_wires; a.sigmas = cc->dev_sigmas; a.k_is = cc->dev_k_is; a.zp = zp;
+            for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
+            a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
+            hipLaunchKernelGGL(k_pp_rows, dim3(nblocks), dim3(256), 0, c->stream, a);
+            GLP_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_pp_block_tot, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks);
+            hipLaunchKernelGGL(k_pp_scan_tot, dim3(nch), dim3(256), 0, c->stream, tot, nblocks);
+            hipLaunchKernelGGL(k_pp_apply, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, nch, npp);
+            GLP_HIP(hipGetLastError());
+        }
+        GLP_TRY(batch_build(c, zp, BATCH_VALUES, nzp, lg, rb, (int)d.cap_height, &zb.b));
+    }
+    GLP_TRY(batch_cap_host(c, zb.b, cap));
+    memcpy(proof + L.caps + capn * 4, cap.data(), capn * 32);
+    ch.observe(cap.data(), capn * 4);
+    for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
+
+    // ---- quotient polynomials
+    BatchHolder qb;
+    {
+        int qdb = 0;
+        while ((1u << qdb) < qdf) qdb++;
+        const u32 Rq = 1u << qdb, step = 1u << (rb - qdb);
+        const u32 nchunks = npp + 1, nterms = nch + nch * nchunks + d.num_gate_constraints;
+        std::vector<u64> apow((size_t)nch * nterms);
+        for (u32 i = 0; i < nch; i++) { u64 x = 1; for (u32 k = 0; k < nterms; k++) { apow[(size_t)i * nterms + k] = x; x = mul(x, alphas[i]); } }
+        u64 *dev_apow, *qv, *qV, *qc;
+        GLP_TRY(tmp.get(&dev_apow, apow.size()));
+        GLP_TRY(h2d(c, dev_apow, apow.data(), apow.size() * 8));
+        GLP_TRY(tmp.get(&qv, (size_t)nch * Rq * n));
+        GLP_TRY(tmp.get(&qV, (size_t)nch * Rq * n));
+        GLP_TRY(tmp.get(&qc, (size_t)nch * Rq * n));
+        QArgs a;
+        a.cs = cc->cs->lde; a.wl = wb.b->lde; a.zl = zb.b->lde; a.out = qv;
+        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; a.apow = dev_apow;
+        for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
+        memcpy(a.pih, pih, 32);
+        const u64 WN = root_of_unity(lg + rb), gn = pow(GEN, (u64)n), wR = root_of_unity(rb);
+        for (u32 rq = 0; rq < Rq; rq++) {
+            const u32 r = rq * step;
+            a.shift_r[rq] = mul(GEN, pow(WN, (u64)r));
+            a.zh[rq] = sub(mul(gn, pow(wR, (u64)r)), 1);      // Z_H(g W^(qR + r)) = g^n w_R^r - 1
+            a.zh_inv[rq] = inv(a.zh[rq]);
+        }
+        a.w_n = root_of_unity(lg); a.n_field = (u64)n % P;
+        a.lg = (u32)lg; a.rb = (u32)rb; a.step = step; a.nc = nc; a.nsel = d.num_selectors; a.nr = nr; a.nw = nw;
+        a.nch = nch; a.npp = npp; a.qdf = qdf; a.num_gates = d.num_gates; a.nterms = nterms;
+        a.many_selectors = d.num_selectors > 1;
+        {
+            StageScope st(c, "quotient_eval", 8.0 * n * Rq * (nc + nr + nw + nzp + 2.0 * nch));
+            hipLaunchKernelGGL(k_quotient, dim3(nblk(n), Rq), dim3(256), 0, c->stream, a);
+            GLP_HIP(hipGetLastError());
+        }
+        {
+            StageScope st(c, "quotient_intt", 16.0 * n * Rq * nch);
+            GLP_TRY(intt_values_to_coeffs(c, qv, qV, nch * Rq, lg));
+            QCArgs q;
+            q.V = qV; q.out = qc; q.lg = (u32)lg; q.Rq = Rq;
+            q.wM_inv = inv(root_of_unity(lg + qdb)); q.wR_inv = inv(root_of_unity(qdb)); q.g_inv = inv(GEN);
+            q.rq_inv = inv((u64)Rq);
+            const u64 gni = inv(gn);
+            u64 x = 1;
+            for (u32 cidx = 0; cidx < Rq; cidx++) { q.gn_inv_pow[cidx] = x; x = mul(x, gni); }
+            hipLaunchKernelGGL(k_quotient_combine, dim3(nblk(n), nch), dim3(256), 0, c->stream, q);
+            GLP_HIP(hipGetLastError());
+        }
+        GLP_TRY(batch_build(c, qc, BATCH_COEFFS_BITREV, nch * qdf, lg, rb, (int)d.cap_height, &qb.b));
+    }
+    GLP_TRY(batch_cap_host(c, qb.b, cap));
+    memcpy(proof + L.caps + 2 * capn * 4, cap.data(), capn * 32);
+    ch.observe(cap.data(), capn * 4);
+
+    const ext2 zeta = ch.get_ext();
+    {
+        ext2 zp = zeta;
+        for (int i = 0; i < lg; i++) zp = e_sqr(zp);
+        if (e_eq(zp, e_from(1))) return set_error(GLP_ERR_PROVE, "Opening point is in the subgroup.");
+    }
+    const ext2 zeta_next = e_scale(zeta, root_of_unity(lg));
+
+    // ---- openings
+    const glp_batch *ob[4] = {cc->cs, wb.b, zb.b, qb.b};
+    std::vector<ext2> open[4], zs_next;
+    {
+        StageScope st(c, "openings", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3] + nzp));
+        u64 *zt, *partial;
+        GLP_TRY(tmp.get(&zt, 2 * n));
+        u32 maxc = 0;
+        for (int k = 0; k < 4; k++) maxc = std::max(maxc, ob[k]->ncols);
+        GLP_TRY(tmp.get(&partial, (size_t)maxc * OPEN_BLOCKS * 2));
+        GLP_TRY(zeta_table(c, zeta, lg, zt));
+        for (int k = 0; k < 4; k++) GLP_TRY(open_batch(c, ob[k], zt, partial, open[k]));
+        GLP_TRY(zeta_table(c, zeta_next, lg, zt));
+        std::vector<ext2> all;
+        GLP_TRY(open_batch(c, zb.b, zt, partial, all));
+        zs_next.assign(all.begin(), all.begin() + nch);
+    }
+    {
+        u64 *op = proof + L.openings;
+        size_t o = 0;
+        auto put = [&](ext2 e) { op[o++] = e.a; op[o++] = e.b; };
+        for (u32 k = 0; k < nc + nr; k++) put(open[0][k]);
+        for (u32 k = 0; k < nw; k++) put(open[1][k]);
+        for (u32 k = 0; k < nch; k++) put(open[2][k]);
+        for (u32 k = 0; k < nch; k++) put(zs_next[k]);
+        for (u32 k = 0; k < nch * npp; k++) put(open[2][nch + k]);
+        for (u32 k = 0; k < nch * qdf; k++) put(open[3][k]);
+        const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;
+        const u64 *p_pp = p_zn + 2 * nch, *p_q = p_pp + 2 * nch * npp;
+        ch.observe(p_cs, 2 * (nc + nr)); ch.observe(p_w, 2 * nw); ch.observe(p_zs, 2 * nch);
+        ch.observe(p_pp, 2 * (size_t)nch * npp); ch.observe(p_q, 2 * (size_t)nch * qdf); ch.observe(p_zn, 2 * nch);
+    }
+
+    // ---- FRI: batch polynomial
+    const ext2 alpha = ch.get_ext();
+    u64 *fcoef;      // [2][n] bit-reversed coefficients of the FRI polynomial
+    GLP_TRY(tmp.get(&fcoef, 2 * n));
+    {
+        StageScope st(c, "fri_combine", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3]));
+        size_t total_cols = 0;
+        for (int k = 0; k < 4; k++) total_cols += ob[k]->ncols;
+        std::vector<u64> ap(2 * total_cols);
+        ext2 x = e_from(1), red0 = e_from(0), red1 = e_from(0);
+        size_t j = 0;
+        for (int k = 0; k < 4; k++)
+            for (u32 col = 0; col < ob[k]->ncols; col++, j++) {
+                ap[2 * j] = x.a; ap[2 * j + 1] = x.b;
+                red0 = e_add(red0, e_mul(x, open[k][col]));
+                x = e_mul(x, alpha);
+            }
+        x = e_from(1);
+        for (u32 col = 0; col < nch; col++) { red1 = e_add(red1, e_mul(x, zs_next[col])); x = e_mul(x, alpha); }
+        u64 *dev_ap, *fv;
+        GLP_TRY(tmp.get(&dev_ap, ap.size()));
+        GLP_TRY(h2d(c, dev_ap, ap.data(), ap.size() * 8));
+        GLP_TRY(tmp.get(&fv, 2 * n));
+        FVArgs a;
+        for (int k = 0; k < 4; k++) { a.lde[k] = ob[k]->lde; a.ncols[k] = ob[k]->ncols; }
+        a.apow = dev_ap; a.out = fv; a.red0 = red0; a.red1 = red1; a.zeta = zeta; a.zeta_next = zeta_next;
+        a.shift_acc = e_pow(alpha, nch);
+        a.w_n = root_of_unity(lg); a.g = GEN; a.lg = (u32)lg; a.rb = (u32)rb; a.nch = nch;
+        hipLaunchKernelGGL(k_final_values, dim3(nblk(n)), dim3(256), 0, c->stream, a);
+        GLP_HIP(hipGetLastError());
+        GLP_TRY(intt_values_to_coeffs(c, fv, fcoef, 2, lg));
+        hipLaunchKernelGGL(k_scale_bitrev_pow, dim3(nblk(n), 2), dim3(256), 0, c->stream, fcoef, inv(GEN), (u32)lg);
+        GLP_HIP(hipGetLastError());
+    }
+
+    // ---- FRI commit phase
+    struct Layer { u64 *vals; u64 *dig; u32 lgL, ab; };
+    std::vector<Layer> layers;
+    u64 *cur = fcoef;
+    int lgcur = lg;
+    u64 shift = GEN;
+    {
+        StageScope st(c, "fri_commit", 0.0);
+        for (u32 r = 0; r < d.num_reductions; r++) {
+            const u32 ab = d.reduction_arity_bits[r];
+            const u32 lgL = (u32)(lgcur + rb);
+            const size_t Lsz = (size_t)1 << lgL, nleaves = Lsz >> ab;
+            Layer ly;
+            ly.lgL = lgL; ly.ab = ab;
+            GLP_TRY(tmp.get(&ly.vals, 2 * Lsz));
+            GLP_TRY(tmp.get(&ly.dig, merkle_num_digests(nleaves, (int)d.cap_height) * 4));
+            GLP_TRY(lde_coeffs(c, cur, ly.vals, 2, lgcur, rb, shift));
+            hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab);
+            GLP_HIP(hipGetLastError());
+            GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height));
+            cap.resize((size_t)capn * 4);
+            GLP_TRY(d2h(c, cap.data(), ly.dig + 4 * merkle_cap_offset(nleaves, (int)d.cap_height), (size_t)capn * 32));
+            memcpy(proof + L.fri_caps + (size_t)r * capn * 4, cap.data(), (size_t)capn * 32);
+            ch.observe(cap.data(), (size_t)capn * 4);
+            layers.push_back(ly);
+            const ext2 beta = ch.get_ext();
+            u64 *nxt;
+            const size_t nnew = ((size_t)1 << lgcur) >> ab;
+            GLP_TRY(tmp.get(&nxt, 2 * nnew));
+            hipLaunchKernelGGL(k_fri_fold, dim3(nblk(nnew)), dim3(256), 0, c->stream, cur, nxt, beta, (u32)lgcur, ab);
+            GLP_HIP(hipGetLastError());
+            cur = nxt; lgcur -= (int)ab;
+            shift = pow(shift, (u64)1 << ab);
+        }
+    }
+    // final polynomial (natural coefficient order)
+    {
+        const size_t fl = (size_t)1 << lgcur;
+        if (fl != L.final_len) return set_error(GLP_ERR_ARG, "reduction_arity_bits inconsistent with degree_bits");
+        std::vector<u64> h(2 * fl);
+        GLP_TRY(d2h(c, h.data(), cur, h.size() * 8));
+        for (size_t p = 0; p < fl; p++) {
+            const size_t k = bitrev32((u32)p, lgcur);
+            proof[L.final_poly + 2 * k] = h[p];
+            proof[L.final_poly + 2 * k + 1] = h[fl + p];
+        }
+        ch.observe(proof + L.final_poly, 2 * fl);
+    }
+    // ---- proof of work
+    {
+        StageScope st(c, "fri_pow", 0.0);
+        PowArgs a;
+        memcpy(a.st, ch.st, 96);
+        for (int i = 0; i < ch.nin; i++) a.st[i] = ch.in[i];
+        a.pos = (u32)ch.nin; a.bits = d.proof_of_work_bits;
+        u64 *best;
+        GLP_TRY(tmp.get(&best, 1));
+        a.best = (unsigned long long *)best;
+        const u64 none = ~0ull;
+        u64 found = none;
+        const u64 batch = 1ull << 20;
+        for (u64 base = 0; found == none; base += batch) {
+            if (base >= (1ull << 40)) return set_error(GLP_ERR_PROVE, "Proof of work failed. This is highly unlikely!");
+            GLP_TRY(h2d(c, best, &none, 8));
+            a.base = base;
+            hipLaunchKernelGGL(k_pow, dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, a);
+            GLP_HIP(hipGetLastError());
+            GLP_TRY(d2h(c, &found, best, 8));
+        }
+        proof[L.pow] = found;
+        ch.observe(&found, 1);
+        const u64 resp = ch.get();
+        if (d.proof_of_work_bits && (resp >> (64 - d.proof_of_work_bits)) != 0)
+            return set_error(GLP_ERR_PROVE, "proof-of-work response check failed");
+    }
+    // ---- query phase
+    {
+        StageScope st(c, "fri_queries", 0.0);
+        const u32 nq = d.num_query_rounds;
+        std::vector<u64> xi(nq);
+        for (u32 q = 0; q < nq; q++) xi[q] = ch.get() % (u64)N;
+        u64 *dev_idx, *dev_buf;
+        GLP_TRY(tmp.get(&dev_idx, nq));
+        size_t maxbuf = 0;
+        for (int k = 0; k < 4; k++) maxbuf = std::max(maxbuf, (size_t)nq * std::max<size_t>(ob[k]->ncols, 4 * (size_t)L.depth0));
+        for (auto &ly : layers) maxbuf = std::max(maxbuf, (size_t)nq * std::max<size_t>((size_t)2 << ly.ab, 4 * (size_t)(ly.lgL - ly.ab)));
+        GLP_TRY(tmp.get(&dev_buf, maxbuf + 8));
+        std::vector<u64> h(maxbuf + 8);
+        GLP_TRY(h2d(c, dev_idx, xi.data(), nq * 8));
+        size_t off = 0;   // word offset inside one query record
+        for (int k = 0; k < 4; k++) {
+            const u32 ncol = ob[k]->ncols;
+            GLP_TRY(merkle_gather_lde_rows(c, ob[k]->lde, ncol, lg, rb, dev_idx, nq, dev_buf));
+            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * ncol * 8));
+            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * ncol, (size_t)ncol * 8);
+            off += ncol;
+            GLP_TRY(merkle_gather_paths(c, ob[k]->digests, N, (int)d.cap_height, dev_idx, nq, dev_buf));
+            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * L.depth0 * 32));
+            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * L.depth0 * 4, (size_t)L.depth0 * 32);
+            off += 4 * (size_t)L.depth0;
+        }
+        for (size_t r = 0; r < layers.size(); r++) {
+            const Layer &ly = layers[r];
+            const u32 arity = 1u << ly.ab, depth = L.step_depth[r];
+            const size_t nleaves = ((size_t)1 << ly.lgL) >> ly.ab;
+            for (u32 q = 0; q < nq; q++) xi[q] >>= ly.ab;
+            GLP_TRY(h2d(c, dev_idx, xi.data(), nq * 8));
+            hipLaunchKernelGGL(k_fri_gather_leaf, dim3(nblk((size_t)nq * arity)), dim3(256), 0, c->stream, ly.vals, ly.lgL, (u32)rb,
+                               ly.ab, dev_idx, nq, dev_buf);
+            GLP_HIP(hipGetLastError());
+            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * arity * 16));
+            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * arity * 2, (size_t)arity * 16);
+            off += 2 * (size_t)arity;
+            GLP_TRY(merkle_gather_paths(c, ly.dig, nleaves, (int)d.cap_height, dev_idx, nq, dev_buf));
+            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * depth * 32));
+            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * depth * 4, (size_t)depth * 32);
+            off += 4 * (size_t)depth;
+        }
+    }
+    return GLP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+void glp_circuit_free(glp_circuit *cc) {
+    if (!cc) return;
+    glp_ctx *c = cc->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    batch_destroy(cc->cs);
+    c->release(cc->dev_sigmas);
+    c->release(cc->dev_k_is);
+    c->release(cc->dev_gates);
+    delete cc;
+}
+
+int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **out) {
+    GLP_REQUIRE(c && desc && out, "null argument");
+    *out = nullptr;
+    GLP_TRY(bind(c));
+    const glp_circuit_desc &d = *desc;
+    GLP_REQUIRE(d.gates && d.k_is && d.constants && d.sigmas, "null array in circuit description");
+    GLP_REQUIRE(d.num_challenges >= 1 && d.num_challenges <= (u32)MAXCH, "num_challenges=%u outside 1..%d", d.num_challenges, MAXCH);
+    GLP_REQUIRE(d.rate_bits >= 1 && d.rate_bits <= 4, "rate_bits=%u outside 1..4", d.rate_bits);
+    GLP_REQUIRE(d.num_routed_wires <= d.num_wires && d.num_routed_wires > 0, "bad wire counts");
+    if ((int)d.degree_bits > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "degree_bits=%u > %d", d.degree_bits, NTT_MAX_LG);
+    const u32 qdf = d.quotient_degree_factor;
+    if (qdf == 0 || (qdf & (qdf - 1)) || qdf > (1u << d.rate_bits))
+        return set_error(GLP_ERR_UNSUPPORTED, "quotient_degree_factor=%u must be a power of two <= 2^rate_bits", qdf);
+    GLP_REQUIRE(d.num_partial_products == (d.num_routed_wires + qdf - 1) / qdf - 1, "num_partial_products inconsistent");
+    GLP_REQUIRE(d.num_reductions <= 16 && d.cap_height <= d.degree_bits + d.rate_bits, "bad FRI parameters");
+    GLP_REQUIRE(d.proof_of_work_bits < 40, "proof_of_work_bits too large");
+    u32 sum_ab = 0;
+    for (u32 i = 0; i < d.num_reductions; i++) {
+        GLP_REQUIRE(d.reduction_arity_bits[i] >= 1 && d.reduction_arity_bits[i] <= 5, "arity_bits outside 1..5");
+        sum_ab += d.reduction_arity_bits[i];
+        GLP_REQUIRE(sum_ab <= d.degree_bits && d.degree_bits + d.rate_bits - sum_ab >= d.cap_height, "FRI reduction deeper than the domain");
+    }
+    u32 maxc = 0;
+    for (u32 i = 0; i < d.num_gates; i++) {
+        const glp_gate &g = d.gates[i];
+        switch (g.type) {
+        case GLP_GATE_NOOP: case GLP_GATE_CONSTANT: case GLP_GATE_PUBLIC_INPUT: case GLP_GATE_ARITHMETIC:
+        case GLP_GATE_U32_INTERLEAVE: case GLP_GATE_UNINTERLEAVE_U32: case GLP_GATE_UNINTERLEAVE_B32: break;
+        default: return set_error(GLP_ERR_UNSUPPORTED, "gate type %u is not built into the quotient kernel yet", g.type);
+        }
+        GLP_REQUIRE(g.selector_index < d.num_selectors && g.group_start <= g.row && g.row < g.group_end, "bad selector data for gate %u", i);
+        maxc = std::max(maxc, g.num_constraints);
+    }
+    GLP_REQUIRE(maxc <= d.num_gate_constraints, "num_gate_constraints smaller than a gate's constraint count");
+
+    std::unique_ptr<glp_circuit, void (*)(glp_circuit *)> cc(new glp_circuit(), glp_circuit_free);
+    cc->ctx = c;
+    cc->d = d;
+    cc->gates.assign(d.gates, d.gates + d.num_gates);
+    cc->k_is.assign(d.k_is, d.k_is + d.num_routed_wires);
+    cc->d.gates = cc->gates.data(); cc->d.k_is = cc->k_is.data(); cc->d.constants = nullptr; cc->d.sigmas = nullptr;
+    make_layout(cc->d, cc->L);
+    const size_t n = (size_t)1 << d.degree_bits;
+    const u32 nc = d.num_constants, nr = d.num_routed_wires;
+    GLP_TRY(c->alloc((void **)&cc->dev_gates, sizeof(DevGate) * std::max<u32>(d.num_gates, 1)));
+    GLP_TRY(c->alloc((void **)&cc->dev_k_is, (size_t)nr * 8));
+    GLP_TRY(c->alloc((void **)&cc->dev_sigmas, (size_t)nr * n * 8));
+    static_assert(sizeof(DevGate) == sizeof(glp_gate), "gate layout");
+    GLP_TRY(h2d(c, cc->dev_gates, cc->gates.data(), sizeof(DevGate) * d.num_gates));
+    GLP_TRY(h2d(c, cc->dev_k_is, cc->k_is.data(), (size_t)nr * 8));
+    GLP_TRY(h2d(c, cc->dev_sigmas, d.sigmas, (size_t)nr * n * 8));
+    {
+        void *v = nullptr;
+        GLP_TRY(c->alloc(&v, (size_t)(nc + nr) * n * 8));
+        u64 *csv = (u64 *)v;
+        int rc = h2d(c, csv, d.constants, (size_t)nc * n * 8);
+        if (rc == GLP_OK) {
+            hipError_t e = hipMemcpyAsync(csv + (size_t)nc * n, cc->dev_sigmas, (size_t)nr * n * 8, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "D2D copy: %s", hipGetErrorString(e));
+        }
+        if (rc == GLP_OK) rc = batch_build(c, csv, BATCH_VALUES, nc + nr, (int)d.degree_bits, (int)d.rate_bits, (int)d.cap_height, &cc->cs);
+        (void)hipStreamSynchronize(c->stream);
+        c->release(v);
+        GLP_TRY(rc);
+    }
+    GLP_TRY(batch_cap_host(c, cc->cs, cc->cs_cap));
+    bool zero = true;
+    for (int i = 0; i < 4; i++) zero = zero && d.circuit_digest[i] == 0;
+    if (zero) {
+        // hash_pad([]) = hash_no_pad([1, 0 x 10, 1]); digest = hash_no_pad(cap ++ that ++ [degree_bits])
+        u64 pad[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, ds[4];
+        host_hash_no_pad(pad, 12, ds);
+        std::vector<u64> parts(cc->cs_cap);
+        parts.insert(parts.end(), ds, ds + 4);
+        parts.push_back(d.degree_bits);
+        host_hash_no_pad(parts.data(), parts.size(), cc->digest);
+    } else {
+        memcpy(cc->digest, d.circuit_digest, 32);
+    }
+    memcpy(cc->d.circuit_digest, cc->digest, 32);
+    *out = cc.release();
+    return GLP_OK;
+}
+
+int glp_circuit_digest(const glp_circuit *cc, uint64_t out[4]) {
+    GLP_REQUIRE(cc && out, "null argument");
+    memcpy(out, cc->digest, 32);
+    return GLP_OK;
+}
+int glp_circuit_constants_sigmas_cap(const glp_circuit *cc, uint64_t *cap_out) {
+    GLP_REQUIRE(cc && cap_out, "null argument");
+    memcpy(cap_out, cc->cs_cap.data(), cc->cs_cap.size() * 8);
+    return GLP_OK;
+}
+size_t glp_proof_words(const glp_circuit *cc) { return cc ? cc->L.total : 0; }
+
+int glp_prove_device(glp_ctx *c, const glp_circuit *cc, const uint64_t *dev_wires, const uint64_t *public_inputs, uint64_t *proof_out) {
+    GLP_REQUIRE(c && cc && dev_wires && proof_out, "null argument");
+    GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");
+    GLP_REQUIRE(public_inputs || cc->d.num_public_inputs == 0, "public_inputs is null");
+    GLP_TRY(bind(c));
+    return prove_impl(c, cc, dev_wires, public_inputs, proof_out);
+}
+
+int glp_prove(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, const uint64_t *public_inputs, uint64_t *proof_out) {
+    GLP_REQUIRE(c && cc && wires && proof_out, "null argument");
+    GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");
+    GLP_TRY(bind(c));
+    const size_t tot = (size_t)cc->d.num_wires << cc->d.degree_bits;
+    void *dv = nullptr;
+    GLP_TRY(c->alloc(&dv, tot * 8));
+    int rc = h2d(c, dv, wires, tot * 8);
+    if (rc == GLP_OK) rc = glp_prove_device(c, cc, (const u64 *)dv, public_inputs, proof_out);
+    (void)hipStreamSynchronize(c->stream);
+    c->release(dv);
+    return rc;
+}
+
+}  // extern "C"

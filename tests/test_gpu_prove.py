@@ -1,0 +1,104 @@
+"""GPU parity tests for the whole prove() path (partial products, quotient, openings, FRI commit,
+proof of work, queries): every word of the HIP library's proof must equal the CPU oracle's, and the
+oracle's verifier must accept it."""
+import numpy as np
+import pytest
+
+import plonky2_lib_amd as glp
+import plonky2_lib_amd.synth as synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = glp.Context(0)
+    yield c
+    c.close()
+
+
+def _sections(oc, desc):
+    """name -> slice of the proof words (layout: include/glp.h)."""
+    cap = 4 << desc.cap_height
+    nch = desc.num_challenges
+    nopen = (desc.num_constants + desc.num_routed_wires + desc.num_wires + 2 * nch + nch * desc.num_partial_products +
+             nch * desc.quotient_degree_factor)
+    o = 0
+    out = {}
+    for name, ln in (("wires_cap", cap), ("zs_pp_cap", cap), ("quotient_cap", cap), ("openings", 2 * nopen),
+                     ("fri_caps", cap * len(desc.reduction_arity_bits))):
+        out[name] = slice(o, o + ln); o += ln
+    out["rest"] = slice(o, None)
+    return out
+
+
+def _check(ctx, oracle, desc):
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    assert (gc.constants_sigmas_cap() == oc.cs_cap).all()
+    assert (gc.digest() == np.asarray(desc.circuit_digest, np.uint64)).all()
+    assert gc.proof_words == oc.proof_words
+    rc, ref = oc.prove()
+    assert rc == 0 and oc.verify(ref) == 0
+    got = gc.prove()
+    sec = _sections(oc, desc)
+    for name, sl in sec.items():
+        assert (got[sl] == ref[sl]).all(), "first mismatch in section %s at word %d" % (
+            name, sl.start + int(np.argmax(got[sl] != ref[sl])))
+    assert oc.verify(got) == 0
+    return oc, gc, got
+
+
+@pytest.mark.parametrize("lg,cfg", [(5, "ecc"), (6, "rec"), (9, "ecc"), (12, "rec"), (13, "ecc")])
+def test_prove_parity_arith(ctx, oracle, lg, cfg):
+    config = synth.Config.standard_ecc_config() if cfg == "ecc" else synth.Config.standard_recursion_config()
+    desc = synth.arith_circuit(lg, config, seed=100 + lg)
+    _check(ctx, oracle, desc)
+
+
+def test_prove_parity_public_inputs(ctx, oracle):
+    pi = np.array([5, 6, 7, 8, 9], np.uint64)
+    desc = synth.arith_circuit(7, seed=9, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi))
+    oc, gc, got = _check(ctx, oracle, desc)
+    assert [int(x) for x in got[-5:]] == [5, 6, 7, 8, 9]
+
+
+def test_prove_parity_reference_u32_gates(ctx, oracle):
+    # U32InterleaveGate / UninterleaveToU32Gate / UninterleaveToB32Gate [REF src/u32/gates/*.rs]
+    desc = synth.u32_circuit(6)
+    _check(ctx, oracle, desc)
+    desc = synth.u32_circuit(8, seed=5)
+    _check(ctx, oracle, desc)
+
+
+def test_unsatisfied_witness_fails_verification(ctx, oracle):
+    desc = synth.arith_circuit(7, seed=11)
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    w = desc.wires.copy()
+    w[7, 50] = np.uint64((int(w[7, 50]) + 1) % glp.P)
+    proof = gc.prove(wires=w)
+    assert oc.verify(proof) != 0
+    rc, ref = oc.prove(wires=w)
+    assert (proof == ref).all()       # same (invalid) transcript on both sides
+
+
+def test_prove_properties_2_16(ctx, oracle):
+    """2^16 rows x 136 wires: too slow for the oracle PROVER in a test, so check through the oracle
+    VERIFIER (the relation the reference's tests assert) plus determinism."""
+    desc = synth.arith_circuit(16, synth.Config.standard_ecc_config(), seed=16)
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    p1 = gc.prove()
+    assert oc.verify(p1) == 0
+    assert (gc.prove() == p1).all()
+    bad = p1.copy(); bad[1000] = np.uint64((int(bad[1000]) + 1) % glp.P)
+    assert oc.verify(bad) != 0
+
+
+def test_unsupported_gate_is_reported(ctx):
+    desc = synth.arith_circuit(5, seed=1)
+    desc.gates[0]["type"] = 4          # PoseidonGate: not in the quotient kernel yet
+    with pytest.raises(glp.GlpError) as e:
+        glp.Circuit(ctx, desc)
+    assert e.value.code == -3

@@ -8,7 +8,7 @@ columns and 16 quotient-chunk columns.  The circuit itself
 here (no Rust, plonky2 fork absent), so the trace is synthetic: SplitMix64-seeded uniform field
 elements of exactly that shape, generated directly in HBM.
 
-One "step" = one proof's worth of the GPU stages implemented so far (see `config.stages`).
+One "step" = one complete prove() (everything after witness generation) from an HBM-resident witness.
 Usage: python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run)
 """
 import argparse
@@ -31,39 +31,41 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="trace rows = 2^log_n (headline: 20)")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=14, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=12, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-SHAPES = (("wires", 136, True), ("zs_partial_products", 20, True), ("quotient_chunks", 16, False))
+SHAPES = (("wires", 136), ("zs_partial_products", 20), ("quotient_chunks", 16))
+BATCH_STAGES = ("intt", "copy_coeffs", "bitrev_coeffs", "lde", "merkle_leaves", "merkle_levels")
 
 
 def cpu_baseline(sample_log_n, full_log_n):
-    """Times the oracle (CPU restatement, kind="port") on a bounded sample of the same workload:
-    the same three PolynomialBatch commitments on 2^sample_log_n rows, all host cores (OpenMP)."""
-    import numpy as np
+    """Times the oracle (CPU restatement of plonky2's prove(), kind="port") on a bounded sample of the
+    same workload: the same synthetic ECDSA-shaped circuit with 2^sample_log_n rows.  Commit stages
+    use all host cores through OpenMP; the remaining stages of the port are single-threaded."""
     from oracle import oracle
-    import plonky2_lib_amd as glp
+    import plonky2_lib_amd.synth as synth
     oracle.build()
     cores = oracle.max_threads()
-    n = 1 << sample_log_n
-    t = 0.0
-    for i, (_, ncols, from_values) in enumerate(SHAPES):
-        x = glp.splitmix_field(SEED + i, ncols * n).reshape(ncols, n)
-        t0 = time.perf_counter()
-        (oracle.batch_from_values if from_values else oracle.batch_from_coeffs)(x, 3, 4)
-        t += time.perf_counter() - t0
+    desc = synth.arith_circuit(sample_log_n, synth.Config.standard_ecc_config(), seed=SEED)
+    oc = oracle.OracleCircuit(desc)
+    t0 = time.perf_counter()
+    rc, proof = oc.prove()
+    t = time.perf_counter() - t0
+    assert rc == 0
     frac = float(1 << sample_log_n) / float(1 << full_log_n)
     return {"value": frac / t, "unit": "proofs/sec", "cores": cores, "kind": "port",
-            "sample": "oracle PolynomialBatch commits (136+20+16 cols) on 2^%d of 2^%d rows, %.2f s wall, "
-                      "scaled linearly by row count" % (sample_log_n, full_log_n, t)}
+            "sample": "oracle prove() of the same synthetic circuit at 2^%d of 2^%d rows: %.2f s wall, scaled "
+                      "linearly by row count" % (sample_log_n, full_log_n, t)}
 
 
 def main():
     a = parse()
+    import numpy as np
     import torch
     import plonky2_lib_amd as glp
+    import plonky2_lib_amd.synth as synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -83,23 +85,17 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     lg = a.log_n
-    n = 1 << lg
     ctx = glp.Context(local_rank)
-    # HBM-resident synthetic inputs (independent proofs per rank: seed differs by rank)
-    inputs = []
-    for i, (name, ncols, from_values) in enumerate(SHAPES):
-        t = torch.empty((ncols, n), dtype=torch.int64, device=dev)
-        ctx.fill_random_device(t.data_ptr(), ncols * n, SEED + i + 1000 * rank)
-        inputs.append((name, ncols, from_values, t))
-    ctx.synchronize()
+    # One independent proof per rank: same circuit, rank-specific witness seed.  Circuit construction
+    # (the reference's `builder.build()`) and witness generation are CPU work outside the timed region.
+    desc = synth.arith_circuit(lg, synth.Config.standard_ecc_config(), seed=SEED + 1000 * rank)
+    circuit = glp.Circuit(ctx, desc)
+    wires = torch.from_numpy(desc.wires.view(np.int64)).to(dev)     # HBM resident before timing starts
+    desc.constants = desc.sigmas = None
+    torch.cuda.synchronize()
 
     def step():
-        batches = []
-        for name, ncols, from_values, t in inputs:
-            f = ctx.batch_from_values_device if from_values else ctx.batch_from_coeffs_device
-            batches.append(f(t.data_ptr(), ncols, lg, 3, 4))
-        for b in batches:
-            b.free()
+        return circuit.prove_device(wires.data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
@@ -113,7 +109,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        proof = step()
     ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -123,11 +119,21 @@ def main():
         dt = float(tt.item())
 
     # per-stage device times (hipEvents on the library's own stream), averaged per launch
-    stages = {}
-    order = []
-    per_step = len(ctx.stages()) // max(a.steps, 1)
-    for idx, (name, ms, by) in enumerate(ctx.stages()):
-        key = "%s/%s" % (SHAPES[(idx % per_step) // (per_step // len(SHAPES))][0], name)
+    raw = ctx.stages()
+    per_step = len(raw) // max(a.steps, 1)
+    stages, order = {}, []
+    for idx, (name, ms, by) in enumerate(raw):
+        pos = idx % per_step
+        if pos == 0:
+            seen = {}
+        if name in BATCH_STAGES:
+            k = seen.get(name, 0)
+            seen[name] = k + 1
+            if name in ("copy_coeffs", "bitrev_coeffs"):
+                k = 2
+            key = "%s/%s" % (SHAPES[min(k, 2)][0], name)
+        else:
+            key = name
         if key not in stages:
             stages[key] = [0.0, 0, by]
             order.append(key)
@@ -137,11 +143,13 @@ def main():
     for k in order:
         ms_avg = stages[k][0] / stages[k][1]
         stage_out[k] = {"ms": round(ms_avg, 4), "alg_GB": round(stages[k][2] / 1e9, 4),
-                        "GBps": round(stages[k][2] / 1e9 / (ms_avg / 1e3), 1) if ms_avg > 0 else None}
+                        "GBps": round(stages[k][2] / 1e9 / (ms_avg / 1e3), 1) if ms_avg > 0 and stages[k][2] else None}
     dom = max(order, key=lambda k: stage_out[k]["ms"])
     ach = stage_out[dom]["GBps"]
-    ntt_merkle_bytes = sum(stages[k][2] for k in order)
-    ntt_merkle_ms = sum(stage_out[k]["ms"] for k in order)
+    nm = [k for k in order if k.split("/")[-1] in ("intt", "lde", "merkle_leaves", "merkle_levels")]
+    nm_bytes = sum(stages[k][2] for k in nm)
+    nm_ms = sum(stage_out[k]["ms"] for k in nm)
+    gpu_ms = sum(stage_out[k]["ms"] for k in order)
 
     if rank == 0:
         out = {
@@ -158,11 +166,12 @@ def main():
             "dtype": "u64 (Goldilocks, 64-bit modular integer)",
             "data": "synthetic",
             "config": {
-                "workload": "secp256k1 ECDSA-verify batch-20 trace shape: 2^%d rows x 136 wires, 20 zs/partial-product "
-                            "cols, 16 quotient-chunk cols; rate_bits 3, cap_height 4; one independent proof per GPU" % lg,
-                "stages": "PARTIAL PROOF: iNTT + LDE + Poseidon Merkle commit of the wires, zs/partial-products and "
-                          "quotient oracles (prove() steps 3, 6, 9 of SURVEY section 3.2); quotient evaluation, openings and "
-                          "FRI are not yet in the timed step",
+                "workload": "ECDSA-verify-shaped circuit (standard_ecc_config: 2^%d rows x 136 wires, 80 routed, 2 challenges, "
+                            "rate_bits 3, cap_height 4, 28 FRI queries, 16 PoW bits; ArithmeticGate/ConstantGate/"
+                            "PublicInputGate/NoopGate rows with copy constraints); one full prove() per step from an HBM-"
+                            "resident witness: wires commit, partial products, quotient, openings, FRI, PoW, queries" % lg,
+                "note": "the real secp256k1 circuit needs the Rust builder (absent); its gate set (U32/BaseSum/RandomAccess/"
+                        "Comparison gates) costs more in the quotient stage than this stand-in's ArithmeticGate rows",
                 "parallelism": "independent proofs sharded one per GPU, no collective",
             },
             "roofline": {
@@ -173,17 +182,19 @@ def main():
                 "unit": "GB/s",
                 "frac": (ach / HBM_PEAK_GBS) if ach else None,
                 "traffic": None,
-                "note": "Poseidon leaf hashing is VALU-bound (about 58k lane-clocks per permutation measured, "
-                        "profiles/r01_ubench_int_issue.txt); HBM fraction is reported as the contract asks",
-                "ntt_plus_merkle": {"alg_GB": round(ntt_merkle_bytes / 1e9, 3), "ms": round(ntt_merkle_ms, 3),
-                                    "GBps": round(ntt_merkle_bytes / 1e9 / (ntt_merkle_ms / 1e3), 1),
-                                    "frac": round(ntt_merkle_bytes / 1e9 / (ntt_merkle_ms / 1e3) / HBM_PEAK_GBS, 4)},
+                "note": "the dominant kernel (Poseidon leaf hashing) is VALU-bound, not HBM-bound: see DESIGN.md; "
+                        "HBM fraction reported as the contract asks",
+                "ntt_plus_merkle": {"alg_GB": round(nm_bytes / 1e9, 3), "ms": round(nm_ms, 3),
+                                    "GBps": round(nm_bytes / 1e9 / (nm_ms / 1e3), 1),
+                                    "frac": round(nm_bytes / 1e9 / (nm_ms / 1e3) / HBM_PEAK_GBS, 4)},
+                "gpu_stage_ms_sum": round(gpu_ms, 3),
                 "stages": stage_out,
             },
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample_log_n, lg), lg)
         print(json.dumps(out))
+    circuit.free()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -47,8 +47,28 @@ def _reduce128(lo, hi):
         return np.where(t2 >= _P, t2 - _P, t2)
 
 
+_CHUNK = 1 << 16
+
+
 def mul(a, b):
+    """Elementwise product.  Large inputs are processed in cache-sized chunks on a thread pool (numpy
+    releases the GIL), which is what makes 2^20-row circuit generation take seconds, not minutes."""
     a, b = np.broadcast_arrays(_u(a), _u(b))
+    if a.size > 4 * _CHUNK:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        fa, fb = np.ascontiguousarray(a).reshape(-1), np.ascontiguousarray(b).reshape(-1)
+        out = np.empty(fa.size, dtype=np.uint64)
+
+        def work(lo):
+            out[lo:lo + _CHUNK] = _mul_small(fa[lo:lo + _CHUNK], fb[lo:lo + _CHUNK])
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+            list(ex.map(work, range(0, fa.size, _CHUNK)))
+        return out.reshape(a.shape)
+    return _mul_small(a, b)
+
+
+def _mul_small(a, b):
     with np.errstate(over="ignore"):
         a0, a1, b0, b1 = a & _M32, a >> _S32, b & _M32, b >> _S32
         p00, p01, p10, p11 = a0 * b0, a0 * b1, a1 * b0, a1 * b1

@@ -46,7 +46,8 @@ GLF_HD void mds_layer(u64 s[12]) {
     }
 }
 
-GLF_HD void permute(u64 s[12]) {
+// Reference schedule (host transcript; also the definition the device path is tested against).
+GLF_HD void permute_ref(u64 s[12]) {
     int rc = 0;
     for (int r = 0; r < 4; r++) {
 #pragma unroll
@@ -68,6 +69,109 @@ GLF_HD void permute(u64 s[12]) {
         mds_layer(s);
     }
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 schedule ---------------------------------------------------------------------------
+// Same permutation, restructured for the VALU (the kernel is integer-issue bound, not HBM bound):
+//  * values between layers are ANY u64 congruent to the field element (no canonicalisation until
+//    the end), so no layer contains a compare-and-subtract;
+//  * the next round's constant layer is folded into the MDS accumulators' initial value, so the
+//    only stand-alone modular additions are the 12 of round 0;
+//  * reductions are written on 32-bit limbs with carry builtins (v_add_co/v_addc chains) instead
+//    of 64-bit compares + selects.
+// Measured (profiles/r01_ubench_int_issue.txt): v_mad_u64_u32 and v_lshl_add_u64 issue at half
+// rate on gfx950, so one MDS row (24 multiply-adds by 6-bit constants + one 96-bit fold) is the
+// dominant cost.
+static __device__ const u64 RC_ZERO[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ u64 fold128_nc(u32 l0, u32 l1, u32 h0, u32 h1) {   // l + 2^64 h  ->  u64, not canonical
+    u32 c, c2, k, k2;
+    u32 t0lo = __builtin_subc(l0, h1, 0u, &c);          // l - h1          (2^96 = -1)
+    u32 t0hi = __builtin_subc(l1, 0u, c, &c);
+    const u32 m = 0u - c;                               // borrow: subtract 2^64 mod p = 2^32 - 1
+    t0lo = __builtin_subc(t0lo, m, 0u, &c2);
+    t0hi = __builtin_subc(t0hi, 0u, c2, &c2);
+    const u32 t1lo = 0u - h0, t1hi = h0 - (h0 != 0);    // h0 * (2^32 - 1)
+    u32 rlo = __builtin_addc(t0lo, t1lo, 0u, &k);
+    u32 rhi = __builtin_addc(t0hi, t1hi, k, &k);
+    const u32 m2 = 0u - k;                              // carry: add 2^32 - 1
+    rlo = __builtin_addc(rlo, m2, 0u, &k2);
+    rhi = __builtin_addc(rhi, 0u, k2, &k2);
+    return ((u64)rhi << 32) | rlo;
+}
+__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    const u64 p10 = (u64)a1 * b0 + (u32)p01;
+    const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return fold128_nc((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+}
+__device__ __forceinline__ u64 sbox7_nc(u64 x) {
+    const u64 x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
+    return mul_nc(x3, x4);
+}
+__device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
+    const u32 t1lo = 0u - h, t1hi = h - (h != 0);
+    u32 k, k2;
+    u32 rlo = __builtin_addc((u32)l, t1lo, 0u, &k);
+    u32 rhi = __builtin_addc((u32)(l >> 32), t1hi, k, &k);
+    const u32 m2 = 0u - k;
+    rlo = __builtin_addc(rlo, m2, 0u, &k2);
+    rhi = __builtin_addc(rhi, 0u, k2, &k2);
+    return ((u64)rhi << 32) | rlo;
+}
+// s <- MDS * s + rc   (rc = the NEXT round's constants), inputs and outputs non-canonical
+__device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        u64 al = (u32)rc[r], ah = rc[r] >> 32;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            al += (u64)lo[(i + r) % 12] * C[i];
+            ah += (u64)hi[(i + r) % 12] * C[i];
+        }
+        if (r == 0) { al += (u64)lo[0] * 8; ah += (u64)hi[0] * 8; }
+        u32 k;
+        const u32 x1 = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &k);
+        const u32 h = (u32)(ah >> 32) + k;
+        s[r] = fold96_nc(((u64)x1 << 32) | (u32)al, h);
+    }
+}
+__device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonical out
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[i]);
+    int rc = 12;
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7_nc(s[i]);
+        mds_add_nc(s, RC + rc);
+        rc += 12;
+    }
+    for (int r = 0; r < 22; r++) {
+        s[0] = sbox7_nc(s[0]);
+        mds_add_nc(s, RC + rc);
+        rc += 12;
+    }
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = sbox7_nc(s[i]);
+        mds_add_nc(s, RC + rc);
+        rc += 12;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = sbox7_nc(s[i]);
+    mds_add_nc(s, RC_ZERO);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
+}
+#else
+inline void permute(u64 s[12]) { permute_ref(s); }
+#endif
 
 // hashing.rs `compress` (= Hasher::two_to_one): perm(l || r || 0000)[0..4]
 GLF_HD void two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {

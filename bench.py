@@ -66,21 +66,12 @@ def main():
     import torch
     import plonky2_lib_amd as glp
     import plonky2_lib_amd.synth as synth
+    import plonky2_lib_amd.dist as gdist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libglprover has no CPU path")
+    grp = gdist.init_from_env(use_cuda=True)
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -97,26 +88,15 @@ def main():
     def step():
         return circuit.prove_device(wires.data_ptr())
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
     for _ in range(a.warmup):
         step()
     ctx.set_profiling(True)
     ctx.stage_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        proof = step()
-    ctx.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+
+    def device_sync():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+    dt = gdist.timed_steps(grp, step, a.steps, 0, device_sync)
 
     # per-stage device times (hipEvents on the library's own stream), averaged per launch
     raw = ctx.stages()
@@ -196,8 +176,7 @@ def main():
         print(json.dumps(out))
     circuit.free()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,68 @@
+"""One process per GPU, independent proofs per rank, no data-path collective.  torch.distributed is
+used for exactly two things: the barrier that brackets the timed region and the MAX over ranks of
+the elapsed time (bench.py contract).  Backend: "nccl" (= RCCL) on GPUs, "gloo" on CPU (tests)."""
+import os
+import time
+
+
+class Group:
+    def __init__(self, rank=0, local_rank=0, world=1, dist=None, device=None):
+        self.rank, self.local_rank, self.world, self.dist, self.device = rank, local_rank, world, dist, device
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device or "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def init_from_env(use_cuda):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return Group(rank, local_rank, world)
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    device = None
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl" if use_cuda else "gloo", rank=rank, world_size=world)
+    return Group(rank, local_rank, world, dist, device)
+
+
+def proofs_for_rank(total, rank, world):
+    """Shard `total` independent proofs over ranks: contiguous blocks, sizes differ by at most one."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def timed_steps(group, step, steps, warmup, device_sync=lambda: None):
+    """W untimed steps, then exactly K steps bracketed by (device sync + barrier) on both sides;
+    returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    device_sync()
+    group.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    group.barrier()
+    return group.max_over_ranks(time.perf_counter() - t0)

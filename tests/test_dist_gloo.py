@@ -1,0 +1,53 @@
+"""N>1 plumbing on CPU: two gloo ranks run the same timing harness bench.py uses (barrier, K timed
+steps, MAX over ranks) with a stand-in step, and the proof sharding covers every proof exactly once.
+The GPU step itself is covered by the -m gpu tests; no collective exists on the data path."""
+import os
+import socket
+import time
+
+import torch.multiprocessing as mp
+
+import plonky2_lib_amd.dist as gdist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    g = gdist.init_from_env(use_cuda=False)
+    done = []
+
+    def step():
+        time.sleep(0.02 * (rank + 1))          # rank 1 is the slow one
+        done.append(1)
+    dt = gdist.timed_steps(g, step, steps=3, warmup=1)
+    mine = list(gdist.proofs_for_rank(7, rank, world))
+    out.put((rank, dt, len(done), mine))
+    g.close()
+
+
+def test_two_rank_timing_and_sharding():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, dt0, n0, m0), (r1, dt1, n1, m1) = res
+    assert n0 == n1 == 4                        # 1 warmup + 3 timed on every rank
+    assert abs(dt0 - dt1) < 1e-9                # both ranks report the MAX
+    assert dt0 >= 3 * 0.04 * 0.9                # ... which is the slow rank's time
+    assert sorted(m0 + m1) == list(range(7)) and abs(len(m0) - len(m1)) <= 1
+
+
+def test_single_rank_needs_no_process_group():
+    g = gdist.Group()
+    assert gdist.timed_steps(g, lambda: None, 2, 1) >= 0.0
+    assert list(gdist.proofs_for_rank(5, 0, 1)) == [0, 1, 2, 3, 4]

@@ -111,3 +111,11 @@ def test_challenger_duplex(oracle):
     ch2 = oracle.Challenger(); ch2.observe(list(range(8)))
     st2 = oracle.poseidon_permute(np.array(list(range(8)) + [0] * 4, np.uint64))
     assert ch2.get() == int(st2[7])
+
+
+def test_oracle_matches_committed_golden_fixture(oracle):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_5x32.npz"))
+    b = oracle.batch_from_values(g["values"], 3, 2)
+    assert (b.coeffs == g["coeffs"]).all() and (b.leaves == g["leaves"]).all()
+    assert (b.digests == g["digests"]).all() and (b.cap == g["cap"]).all()

@@ -124,6 +124,71 @@ GLF_HD ext2 e_pow(ext2 b, u64 e) {
     return r;
 }
 
+// ---- gfx950 limb forms (device only) -------------------------------------------------------------
+// l + 2^64 h -> some u64 congruent to it (NOT canonical).  32-bit limbs + carry builtins: on gfx950 a
+// 64-bit compare + select costs more issue slots than a v_add_co/v_addc chain.
+__device__ __forceinline__ u64 fold128_nc(u32 l0, u32 l1, u32 h0, u32 h1) {
+    u32 c, c2, k, k2;
+    u32 t0lo = __builtin_subc(l0, h1, 0u, &c);          // l - h1          (2^96 = -1)
+    u32 t0hi = __builtin_subc(l1, 0u, c, &c);
+    const u32 m = 0u - c;                               // borrow: subtract 2^64 mod p = 2^32 - 1
+    t0lo = __builtin_subc(t0lo, m, 0u, &c2);
+    t0hi = __builtin_subc(t0hi, 0u, c2, &c2);
+    const u32 t1lo = 0u - h0, t1hi = h0 - (h0 != 0);    // h0 * (2^32 - 1)
+    u32 rlo = __builtin_addc(t0lo, t1lo, 0u, &k);
+    u32 rhi = __builtin_addc(t0hi, t1hi, k, &k);
+    const u32 m2 = 0u - k;                              // carry: add 2^32 - 1
+    rlo = __builtin_addc(rlo, m2, 0u, &k2);
+    rhi = __builtin_addc(rhi, 0u, k2, &k2);
+    return ((u64)rhi << 32) | rlo;
+}
+// l + 2^64 h, h < 2^32
+__device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
+    const u32 t1lo = 0u - h, t1hi = h - (h != 0);
+    u32 k, k2;
+    u32 rlo = __builtin_addc((u32)l, t1lo, 0u, &k);
+    u32 rhi = __builtin_addc((u32)(l >> 32), t1hi, k, &k);
+    const u32 m2 = 0u - k;
+    rlo = __builtin_addc(rlo, m2, 0u, &k2);
+    rhi = __builtin_addc(rhi, 0u, k2, &k2);
+    return ((u64)rhi << 32) | rlo;
+}
+// any u64 inputs -> non-canonical product
+__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p00 = (u64)a0 * b0;
+    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
+    const u64 p10 = (u64)a1 * b0 + (u32)p01;
+    const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    return fold128_nc((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+}
+// canonical product through the limb form
+__device__ __forceinline__ u64 mul_c(u64 a, u64 b) { return canon(mul_nc(a, b)); }
+// x * 2^E mod p for a compile-time 0 < E < 96 (x any u64) -> canonical.  Every 64th root of unity of
+// the field is +-2^(3j), so the small-radix butterflies of the NTT multiply by shifting.
+template <int E>
+__device__ __forceinline__ u64 mul_pow2_c(u64 x) {
+    static_assert(E > 0 && E < 96, "shift out of range");
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    if constexpr (E < 32) {
+        const u32 y0 = x0 << E, y1 = (x1 << E) | (x0 >> (32 - E)), y2 = x1 >> (32 - E);
+        return canon(fold96_nc(((u64)y1 << 32) | y0, y2));
+    } else if constexpr (E == 32) {
+        return canon(fold128_nc(0u, x0, x1, 0u));
+    } else if constexpr (E < 64) {
+        constexpr int S = E - 32;
+        const u32 y1 = x0 << S, y2 = (x1 << S) | (x0 >> (32 - S)), y3 = x1 >> (32 - S);
+        return canon(fold128_nc(0u, y1, y2, y3));
+    } else if constexpr (E == 64) {
+        return canon(fold128_nc(0u, 0u, x0, x1));
+    } else {
+        // x 2^E = y' 2^64 with y' = x << (E-64) (96 bits):  y'0 (2^32-1) - y'1 - y'2 2^32;  -y'2 2^32 = (~y'2) 2^32 + 1 (mod p)
+        constexpr int S = E - 64;
+        const u32 y0 = x0 << S, y1 = (x1 << S) | (x0 >> (32 - S)), y2 = x1 >> (32 - S);
+        return canon(fold128_nc(1u, ~y2, y0, y1));
+    }
+}
+
 GLF_HD u32 bitrev32(u32 x, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return bits ? (__brev(x) >> (32 - bits)) : 0;

@@ -23,6 +23,7 @@ struct NttPlan {
     int lg, lgA, lgB;
     u64 *tw_B = nullptr, *itw_B = nullptr;   // w_B^j / w_B^-j, j < B/2
     u64 *tw_A = nullptr, *itw_A = nullptr;   // w_A^j / w_A^-j, j < A/2
+    u64 *tw4096 = nullptr, *itw4096 = nullptr;  // w_4096^(+-j), j < 4096: inter-step twiddles of the radix-16 kernels
     u64 w_n, w_n_inv, n_inv;
 };
 

@@ -45,6 +45,17 @@ int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out) {
     GLP_TRY(upload(c, table(p->lgB, true), &p->itw_B));
     GLP_TRY(upload(c, table(p->lgA, false), &p->tw_A));
     GLP_TRY(upload(c, table(p->lgA, true), &p->itw_A));
+    {
+        std::vector<u64> f(4096), b(4096);
+        const u64 w = root_of_unity(12), wi = inv(w);
+        u64 x = 1, y = 1;
+        for (int j = 0; j < 4096; j++) { f[j] = x; b[j] = y; x = mul(x, w); y = mul(y, wi); }
+        GLP_TRY(upload(c, f, &p->tw4096));
+        GLP_TRY(upload(c, b, &p->itw4096));
+        // the radix-16 butterflies hard-code w_16 = 2^156 = -2^60 and w_16^-1 = 2^36
+        if (glf::pow((u64)2, (u64)156) != root_of_unity(4) || glf::pow((u64)2, (u64)36) != inv(root_of_unity(4)))
+            return set_error(GLP_ERR_ARG, "internal: 16th root of unity is not the expected power of two");
+    }
     *out = p.get();
     c->ntt_plans[lg] = p.release();
     return GLP_OK;
@@ -85,6 +96,7 @@ void free_plans(glp_ctx *c) {
     c->lde_plans.clear();
     for (auto &kv : c->ntt_plans) {
         (void)hipFree(kv.second->tw_B); (void)hipFree(kv.second->itw_B); (void)hipFree(kv.second->tw_A); (void)hipFree(kv.second->itw_A);
+        (void)hipFree(kv.second->tw4096); (void)hipFree(kv.second->itw4096);
         delete kv.second;
     }
     c->ntt_plans.clear();
@@ -94,6 +106,7 @@ void free_plans(glp_ctx *c) {
 // kernels
 // ------------------------------------------------------------------------------------------
 constexpr int TPB = 256;
+constexpr int MAXR_LDE = 16;
 constexpr int EPT = (1 << NTT_LGB_MAX) / TPB;   // 16 elements per thread in the contiguous tile
 
 __device__ __forceinline__ u64 dev_pow(u64 b, u32 e) {
@@ -315,6 +328,237 @@ __global__ void k_lde_to_natural(const u64 *__restrict__ in, u64 *__restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------
+// radix-16 register kernels (B = 4096 = 16^3 contiguous, A = 256 = 16^2 strided)
+//
+// Each thread keeps 16 elements in registers and runs a 16-point DFT whose twiddles are the 16th
+// roots of unity, i.e. +-2^(12k): shifts, no multiplier.  A 4096-point tile is three such steps
+// with two LDS exchanges (Cooley-Tukey index map, general twiddles w_4096^(..) between steps),
+// instead of 12 radix-2 stages with a barrier each.
+// ------------------------------------------------------------------------------------------
+template <bool INV, int J> struct W16 {     // w_16^(+-J) = (neg ? -1 : 1) * 2^sh
+    static constexpr int e = ((INV ? 36 : 156) * J) % 192;
+    static constexpr bool neg = e >= 96;
+    static constexpr int sh = e % 96;
+};
+template <bool INV, int J> __device__ __forceinline__ void bf_dit(u64 &u, u64 &v) {   // (u, v) -> (u + w v, u - w v)
+    u64 t;
+    if constexpr (W16<INV, J>::sh == 0) t = v; else t = mul_pow2_c<W16<INV, J>::sh>(v);
+    const u64 a = W16<INV, J>::neg ? sub(u, t) : add(u, t);
+    const u64 b = W16<INV, J>::neg ? add(u, t) : sub(u, t);
+    u = a; v = b;
+}
+template <bool INV, int J> __device__ __forceinline__ void bf_dif(u64 &u, u64 &v) {   // (u, v) -> (u + v, (u - v) w)
+    const u64 a = add(u, v);
+    const u64 d = W16<INV, J>::neg ? sub(v, u) : sub(u, v);
+    if constexpr (W16<INV, J>::sh == 0) v = d; else v = mul_pow2_c<W16<INV, J>::sh>(d);
+    u = a;
+}
+// 16-point DFT, decimation in time: x[bitrev4(k)] in -> X[q] out (natural)
+template <bool INV> __device__ __forceinline__ void dft16_dit(u64 x[16]) {
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) bf_dit<INV, 0>(x[j], x[j + 1]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) { bf_dit<INV, 0>(x[b], x[b + 2]); bf_dit<INV, 4>(x[b + 1], x[b + 3]); }
+#pragma unroll
+    for (int b = 0; b < 16; b += 8) {
+        bf_dit<INV, 0>(x[b], x[b + 4]); bf_dit<INV, 2>(x[b + 1], x[b + 5]);
+        bf_dit<INV, 4>(x[b + 2], x[b + 6]); bf_dit<INV, 6>(x[b + 3], x[b + 7]);
+    }
+    bf_dit<INV, 0>(x[0], x[8]); bf_dit<INV, 1>(x[1], x[9]); bf_dit<INV, 2>(x[2], x[10]); bf_dit<INV, 3>(x[3], x[11]);
+    bf_dit<INV, 4>(x[4], x[12]); bf_dit<INV, 5>(x[5], x[13]); bf_dit<INV, 6>(x[6], x[14]); bf_dit<INV, 7>(x[7], x[15]);
+}
+// 16-point DFT, decimation in frequency: x[i] in (natural) -> X[k] at x[bitrev4(k)]
+template <bool INV> __device__ __forceinline__ void dft16_dif(u64 x[16]) {
+    bf_dif<INV, 0>(x[0], x[8]); bf_dif<INV, 1>(x[1], x[9]); bf_dif<INV, 2>(x[2], x[10]); bf_dif<INV, 3>(x[3], x[11]);
+    bf_dif<INV, 4>(x[4], x[12]); bf_dif<INV, 5>(x[5], x[13]); bf_dif<INV, 6>(x[6], x[14]); bf_dif<INV, 7>(x[7], x[15]);
+#pragma unroll
+    for (int b = 0; b < 16; b += 8) {
+        bf_dif<INV, 0>(x[b], x[b + 4]); bf_dif<INV, 2>(x[b + 1], x[b + 5]);
+        bf_dif<INV, 4>(x[b + 2], x[b + 6]); bf_dif<INV, 6>(x[b + 3], x[b + 7]);
+    }
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) { bf_dif<INV, 0>(x[b], x[b + 2]); bf_dif<INV, 4>(x[b + 1], x[b + 3]); }
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) bf_dif<INV, 0>(x[j], x[j + 1]);
+}
+__device__ __forceinline__ int brev4(int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
+
+constexpr int R16_LDS = 17 * 256;       // 16 x 16 x 16 tile, rows of 16 padded to 17 (bank spread for stride-16 reads)
+
+// Forward contiguous pass, B = 4096 (same contract as k_lde_contig).  k2 = 256 ka + 16 kb + kc is stored at
+// tile slot 256 rc + 16 rb + ra (r* = bitrev4(k*)); q2 = qa + 16 qb + 256 qc.
+__global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ coeffs, u64 *__restrict__ out,
+                                                      const u64 *__restrict__ tw4096, const u64 *__restrict__ pre,
+                                                      const u64 *__restrict__ s_r, u64 w_n, int lg, int lgA, int R) {
+    __shared__ __attribute__((aligned(16))) u64 lds[R16_LDS];
+    __shared__ u64 T0[64], T1[64], sk[MAXR_LDE];
+    constexpr int B = 4096;
+    const int tid = threadIdx.x;
+    const u32 pb = blockIdx.x, col = blockIdx.y;
+    const size_t n = (size_t)1 << lg;
+    if (lgA > 0) {
+        const u32 k1 = bitrev32(pb, lgA);
+        if (tid < 128) {
+            const u64 base = dev_pow(w_n, k1);
+            if (tid < 64) T0[tid] = dev_pow(base, tid);
+            else T1[tid - 64] = dev_pow(base, (u32)(tid - 64) << 6);
+        } else if (tid < 128 + R) {
+            sk[tid - 128] = dev_pow(s_r[tid - 128], k1);
+        }
+    }
+    // step-1 role: tid = 16 rc + rb, owns slots 16 tid .. 16 tid + 15 (ra = 0..15).  The 32-KB coefficient
+    // tile is re-read per coset (L2 hits) rather than held in 32 VGPRs across the coset loop.
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(coeffs + (size_t)col * n + (size_t)pb * B + 16 * tid);
+    __syncthreads();
+    const int hi4 = tid >> 4, lo4 = tid & 15;
+    const int kb1 = brev4(lo4);          // step 1: rb = lo4
+    const int kc2 = brev4(lo4);          // step 2: rc = lo4, qa = hi4
+    for (int r = 0; r < R; r++) {
+        u64 x[16];
+        {
+            const ulonglong2 *pr = reinterpret_cast<const ulonglong2 *>(pre + (size_t)r * B + 16 * tid);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const ulonglong2 v = pr[e], cc = src[e];
+                x[2 * e] = mul_c(cc.x, v.x);
+                x[2 * e + 1] = mul_c(cc.y, v.y);
+            }
+        }
+        dft16_dit<false>(x);                                 // over ka -> qa
+#pragma unroll
+        for (int qa = 0; qa < 16; qa++) {                    // twiddle w_256^(qa kb); slot A1[qa][rc = hi4][rb = lo4]
+            const u64 v = qa == 0 ? x[0] : mul_c(x[qa], tw4096[16 * qa * kb1]);
+            lds[17 * (16 * qa + hi4) + lo4] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 16; rb++) x[rb] = lds[17 * tid + rb];      // step-2 role: tid = 16 qa + rc
+        __syncthreads();
+        dft16_dit<false>(x);                                 // over kb -> qb
+#pragma unroll
+        for (int qb = 0; qb < 16; qb++) {                    // twiddle w_4096^((qa + 16 qb) kc); slot A2[qb][qa][rc]
+            const u64 v = mul_c(x[qb], tw4096[(hi4 + 16 * qb) * kc2]);
+            lds[17 * (hi4 + 16 * qb) + lo4] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rc = 0; rc < 16; rc++) x[rc] = lds[17 * tid + rc];      // step-3 role: tid = qa + 16 qb
+        __syncthreads();
+        dft16_dit<false>(x);                                 // over kc -> qc ; q2 = tid + 256 qc
+        u64 *dst = out + ((size_t)col * R + r) * n + (size_t)pb * B + tid;
+        if (lgA > 0) {
+            const u64 skr = sk[r];
+#pragma unroll
+            for (int qc = 0; qc < 16; qc++) {
+                const int q2 = tid + 256 * qc;
+                dst[256 * qc] = mul_c(x[qc], mul_nc(mul_nc(T1[q2 >> 6], T0[q2 & 63]), skr));
+            }
+        } else {
+#pragma unroll
+            for (int qc = 0; qc < 16; qc++) dst[256 * qc] = x[qc];
+        }
+    }
+}
+
+// Inverse contiguous pass, B = 4096 (same contract as k_intt_contig).  i2 = 256 ia + 16 ib + ic natural in;
+// k2 = ka + 16 kb + 256 kc out at slot 256 ra + 16 rb + rc.
+__global__ __launch_bounds__(TPB) void k_intt_contig16(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                       const u64 *__restrict__ itw4096, u64 w_n_inv, u64 n_inv, int lg,
+                                                       int lgA) {
+    __shared__ __attribute__((aligned(16))) u64 lds[R16_LDS];
+    __shared__ u64 T0[64], T1[64];
+    constexpr int B = 4096;
+    const int tid = threadIdx.x;
+    const u32 pb = blockIdx.x, col = blockIdx.y;
+    const size_t n = (size_t)1 << lg;
+    if (lgA > 0 && tid < 128) {
+        const u32 k1 = bitrev32(pb, lgA);
+        const u64 base = dev_pow(w_n_inv, k1);
+        if (tid < 64) T0[tid] = dev_pow(base, tid);
+        else T1[tid - 64] = mul(dev_pow(base, (u32)(tid - 64) << 6), n_inv);
+    }
+    __syncthreads();
+    const size_t off = (size_t)col * n + (size_t)pb * B;
+    const int hi4 = tid >> 4, lo4 = tid & 15;
+    u64 x[16];
+    // step 1: tid = 16 ib + ic = i2 mod 256; elements ia = 0..15 at i2 = 256 ia + tid
+#pragma unroll
+    for (int ia = 0; ia < 16; ia++) {
+        const int i2 = 256 * ia + tid;
+        const u64 f = lgA > 0 ? mul_nc(T1[i2 >> 6], T0[i2 & 63]) : n_inv;
+        x[ia] = mul_c(in[off + i2], f);
+    }
+    dft16_dif<true>(x);                                      // over ia -> ka at x[ra]
+#pragma unroll
+    for (int ra = 0; ra < 16; ra++) {                        // twiddle w^-(tid ka); slot [ra][ic = lo4][ib = hi4]
+        const int ka = brev4(ra);
+        const u64 v = ka == 0 ? x[ra] : mul_c(x[ra], itw4096[tid * ka]);
+        lds[17 * (16 * ra + lo4) + hi4] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ib = 0; ib < 16; ib++) x[ib] = lds[17 * tid + ib];          // step-2 role: tid = 16 ra + ic
+    __syncthreads();
+    dft16_dif<true>(x);                                      // over ib -> kb at x[rb]
+#pragma unroll
+    for (int rb = 0; rb < 16; rb++) {                        // twiddle w_256^-(ic kb); slot [ra = hi4][rb][ic = lo4]
+        const int kb = brev4(rb);
+        const u64 v = kb == 0 ? x[rb] : mul_c(x[rb], itw4096[16 * lo4 * kb]);
+        lds[17 * (16 * hi4 + rb) + lo4] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ic = 0; ic < 16; ic++) x[ic] = lds[17 * tid + ic];          // step-3 role: tid = 16 ra + rb
+    dft16_dif<true>(x);                                      // over ic -> kc at x[rc]; slot 16 tid + rc
+    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(out + off + 16 * tid);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { ulonglong2 v; v.x = x[2 * e]; v.y = x[2 * e + 1]; dst[e] = v; }
+}
+
+// Strided pass for A = 256: tile 256 rows x 16 columns, thread = (column w, group g).
+//  DIT (forward): row pb = 16 rb + ra holds k1 = 16 ka + kb (r* = bitrev4(k*)); out row q1 = qa + 16 qb.
+//  DIF (inverse): row i1 = 16 ia + ib natural in; out k1 = ka + 16 kb at row 16 ra + rb.
+constexpr int S16_ROW = 272;            // 16 x 16 (+16 pad) words per first-index slab
+template <bool DIF>
+__global__ __launch_bounds__(TPB) void k_strided16(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                   const u64 *__restrict__ tw4096, int lg, int lgB) {
+    __shared__ __attribute__((aligned(16))) u64 lds[16 * S16_ROW];
+    const int tid = threadIdx.x, w = tid & 15, g = tid >> 4;
+    const size_t n = (size_t)1 << lg, B = (size_t)1 << lgB;
+    const size_t base = (size_t)blockIdx.y * n + (size_t)blockIdx.x * NTT_STRIDED_W + w;
+    u64 x[16];
+    if (!DIF) {
+#pragma unroll
+        for (int ra = 0; ra < 16; ra++) x[ra] = in[base + (size_t)(16 * g + ra) * B];     // g = rb
+        dft16_dit<false>(x);                                                              // over ka -> qa
+        const int kb = brev4(g);
+#pragma unroll
+        for (int qa = 0; qa < 16; qa++) lds[qa * S16_ROW + 16 * g + w] = qa == 0 ? x[0] : mul_c(x[qa], tw4096[16 * qa * kb]);
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < 16; rb++) x[rb] = lds[g * S16_ROW + 16 * rb + w];           // g = qa
+        dft16_dit<false>(x);                                                              // over kb -> qb
+#pragma unroll
+        for (int qb = 0; qb < 16; qb++) out[base + (size_t)(g + 16 * qb) * B] = x[qb];
+    } else {
+#pragma unroll
+        for (int ia = 0; ia < 16; ia++) x[ia] = in[base + (size_t)(16 * ia + g) * B];     // g = ib
+        dft16_dif<true>(x);                                                               // over ia -> ka at x[ra]
+#pragma unroll
+        for (int ra = 0; ra < 16; ra++) {
+            const int ka = brev4(ra);
+            lds[ra * S16_ROW + 16 * g + w] = ka == 0 ? x[ra] : mul_c(x[ra], tw4096[16 * g * ka]);   // itw table passed in
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ib = 0; ib < 16; ib++) x[ib] = lds[g * S16_ROW + 16 * ib + w];           // g = ra
+        dft16_dif<true>(x);                                                               // over ib -> kb at x[rb]
+#pragma unroll
+        for (int rb = 0; rb < 16; rb++) out[base + (size_t)(16 * g + rb) * B] = x[rb];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static size_t contig_lds_bytes(int lgB) { return (((size_t)1 << lgB) + ((size_t)1 << lgB) / 2 + 1 + 64 + 64 + 16) * sizeof(u64); }
@@ -327,13 +571,21 @@ int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int l
     const int R = 1 << rate_bits;
     if (ncols > 65535u || (u64)ncols * R > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols*2^rate_bits=%llu exceeds grid.y", (unsigned long long)ncols * R);
     dim3 g1(1u << np->lgA, ncols);
-    hipLaunchKernelGGL(k_lde_contig, g1, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, dev_coeffs, dev_lde, np->tw_B,
-                       lp->pre, lp->s_r, np->w_n, lg, np->lgA, np->lgB, R);
+    if (np->lgB == 12)
+        hipLaunchKernelGGL(k_lde_contig16, g1, dim3(TPB), 0, c->stream, dev_coeffs, dev_lde, np->tw4096, lp->pre, lp->s_r,
+                           np->w_n, lg, np->lgA, R);
+    else
+        hipLaunchKernelGGL(k_lde_contig, g1, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, dev_coeffs, dev_lde, np->tw_B,
+                           lp->pre, lp->s_r, np->w_n, lg, np->lgA, np->lgB, R);
     GLP_HIP(hipGetLastError());
     if (np->lgA > 0) {
         dim3 g2((1u << np->lgB) / NTT_STRIDED_W, ncols * R);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw_A, lg,
-                           np->lgA, np->lgB);
+        if (np->lgA == 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw4096, lg,
+                               np->lgB);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw_A, lg,
+                               np->lgA, np->lgB);
         GLP_HIP(hipGetLastError());
     }
     return GLP_OK;
@@ -351,14 +603,22 @@ int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u3
     const u64 *src = dev_values;
     if (np->lgA > 0) {
         dim3 g1((1u << np->lgB) / NTT_STRIDED_W, ncols);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs, np->itw_A,
-                           lg, np->lgA, np->lgB);
+        if (np->lgA == 8)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs,
+                               np->itw4096, lg, np->lgB);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs, np->itw_A,
+                               lg, np->lgA, np->lgB);
         GLP_HIP(hipGetLastError());
         src = dev_coeffs;
     }
     dim3 g2(1u << np->lgA, ncols);
-    hipLaunchKernelGGL(k_intt_contig, g2, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, src, dev_coeffs, np->itw_B,
-                       np->w_n_inv, np->n_inv, lg, np->lgA, np->lgB);
+    if (np->lgB == 12)
+        hipLaunchKernelGGL(k_intt_contig16, g2, dim3(TPB), 0, c->stream, src, dev_coeffs, np->itw4096, np->w_n_inv, np->n_inv, lg,
+                           np->lgA);
+    else
+        hipLaunchKernelGGL(k_intt_contig, g2, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, src, dev_coeffs, np->itw_B,
+                           np->w_n_inv, np->n_inv, lg, np->lgA, np->lgB);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }

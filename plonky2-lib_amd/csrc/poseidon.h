@@ -84,42 +84,9 @@ GLF_HD void permute_ref(u64 s[12]) {
 // dominant cost.
 static __device__ const u64 RC_ZERO[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-__device__ __forceinline__ u64 fold128_nc(u32 l0, u32 l1, u32 h0, u32 h1) {   // l + 2^64 h  ->  u64, not canonical
-    u32 c, c2, k, k2;
-    u32 t0lo = __builtin_subc(l0, h1, 0u, &c);          // l - h1          (2^96 = -1)
-    u32 t0hi = __builtin_subc(l1, 0u, c, &c);
-    const u32 m = 0u - c;                               // borrow: subtract 2^64 mod p = 2^32 - 1
-    t0lo = __builtin_subc(t0lo, m, 0u, &c2);
-    t0hi = __builtin_subc(t0hi, 0u, c2, &c2);
-    const u32 t1lo = 0u - h0, t1hi = h0 - (h0 != 0);    // h0 * (2^32 - 1)
-    u32 rlo = __builtin_addc(t0lo, t1lo, 0u, &k);
-    u32 rhi = __builtin_addc(t0hi, t1hi, k, &k);
-    const u32 m2 = 0u - k;                              // carry: add 2^32 - 1
-    rlo = __builtin_addc(rlo, m2, 0u, &k2);
-    rhi = __builtin_addc(rhi, 0u, k2, &k2);
-    return ((u64)rhi << 32) | rlo;
-}
-__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 p00 = (u64)a0 * b0;
-    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-    const u64 p10 = (u64)a1 * b0 + (u32)p01;
-    const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-    return fold128_nc((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
-}
 __device__ __forceinline__ u64 sbox7_nc(u64 x) {
     const u64 x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
     return mul_nc(x3, x4);
-}
-__device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
-    const u32 t1lo = 0u - h, t1hi = h - (h != 0);
-    u32 k, k2;
-    u32 rlo = __builtin_addc((u32)l, t1lo, 0u, &k);
-    u32 rhi = __builtin_addc((u32)(l >> 32), t1hi, k, &k);
-    const u32 m2 = 0u - k;
-    rlo = __builtin_addc(rlo, m2, 0u, &k2);
-    rhi = __builtin_addc(rhi, 0u, k2, &k2);
-    return ((u64)rhi << 32) | rlo;
 }
 // s <- MDS * s + rc   (rc = the NEXT round's constants), inputs and outputs non-canonical
 __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {

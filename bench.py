@@ -40,6 +40,19 @@ SHAPES = (("wires", 136), ("zs_partial_products", 20), ("quotient_chunks", 16))
 BATCH_STAGES = ("intt", "copy_coeffs", "bitrev_coeffs", "lde", "merkle_leaves", "merkle_levels")
 
 
+def pmc_traffic(stage_key, log_n):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
+    FETCH_SIZE / WRITE_SIZE runs of this same bench, corrected as profiles/pmc_summary.py documents).
+    Only valid for the configuration the passes were taken on (2^20 rows)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    kernel = {"merkle_leaves": "k_leaf_hash_lde", "lde": "k_strided16<false>", "quotient_eval": "k_quotient"}.get(
+        stage_key.split("/")[-1])
+    if log_n != 20 or kernel is None or not os.path.exists(path):
+        return None
+    rows = [r for r in json.load(open(path))["dispatches"] if kernel in r["kernel"]]
+    return max(r["hbm_bytes"] for r in rows) if rows else None
+
+
 def cpu_baseline(sample_log_n, full_log_n):
     """Times the oracle (CPU restatement of plonky2's prove(), kind="port") on a bounded sample of the
     same workload: the same synthetic ECDSA-shaped circuit with 2^sample_log_n rows.  Commit stages
@@ -161,7 +174,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                "traffic": None,
+                "traffic": pmc_traffic(dom, lg),
+                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                "algorithmic_bytes": stages[dom][2],
                 "note": "the dominant kernel (Poseidon leaf hashing) is VALU-bound, not HBM-bound: see DESIGN.md; "
                         "HBM fraction reported as the contract asks",
                 "ntt_plus_merkle": {"alg_GB": round(nm_bytes / 1e9, 3), "ms": round(nm_ms, 3),

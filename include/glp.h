@@ -119,7 +119,7 @@ enum {
     GLP_GATE_CONSTANT = 1,         /* gates/constant.rs, p0 = num_consts */
     GLP_GATE_PUBLIC_INPUT = 2,     /* gates/public_input.rs */
     GLP_GATE_ARITHMETIC = 3,       /* gates/arithmetic_base.rs, p0 = num_ops */
-    GLP_GATE_POSEIDON = 4,         /* gates/poseidon.rs (not built yet: GLP_ERR_UNSUPPORTED) */
+    GLP_GATE_POSEIDON = 4,         /* gates/poseidon.rs */
     GLP_GATE_U32_INTERLEAVE = 5,   /* [REF src/u32/gates/interleave_u32.rs:33-82,84-135], p0 = num_ops */
     GLP_GATE_UNINTERLEAVE_U32 = 6, /* [REF src/u32/gates/uninterleave_to_u32.rs:30-91,93-150], p0 = num_ops */
     GLP_GATE_UNINTERLEAVE_B32 = 7  /* [REF src/u32/gates/uninterleave_to_b32.rs:95-150], p0 = num_ops */

@@ -70,6 +70,55 @@ static gl2 compute_filter(const glo_gate *g, gl2 s, int many_selectors) {
     if (many_selectors) f = gl2_mul(f, gl2_sub(gl2_from(0xFFFFFFFFull), s)); /* UNUSED_SELECTOR = u32::MAX */
     return f;
 }
+/* gates/poseidon.rs `PoseidonGate::eval_unfiltered`.  plonky2 evaluates the partial rounds in its "fast"
+ * (sparse-matrix) form; the S-box inputs, hence every constraint polynomial, are the same as in the
+ * naive schedule used here (plonky2 asserts the two schedules equal).  Wire layout: inputs 0..11, outputs
+ * 12..23, swap 24, delta 25..28, full_sbox_0(r=1..3) from 29, partial_sbox from 65, full_sbox_1 from 87. */
+#include "poseidon_constants.h"
+static const u64 PG_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+static gl2 gl2_sbox7(gl2 x) { gl2 x2 = gl2_mul(x, x), x4 = gl2_mul(x2, x2), x3 = gl2_mul(x, x2); return gl2_mul(x3, x4); }
+static void gl2_mds(gl2 s[12]) {
+    gl2 o[12];
+    for (int r = 0; r < 12; r++) {
+        gl2 acc = gl2_from(0);
+        for (int i = 0; i < 12; i++) acc = gl2_add(acc, gl2_scale(s[(i + r) % 12], PG_CIRC[i]));
+        if (r == 0) acc = gl2_add(acc, gl2_scale(s[0], 8));
+        o[r] = acc;
+    }
+    memcpy(s, o, sizeof(o));
+}
+static void eval_poseidon_gate(const gl2 *lw, gl2 *out) {
+    u32 k = 0;
+    gl2 swap = lw[24], st[12];
+    out[k++] = gl2_mul(swap, gl2_sub(swap, gl2_from(1)));
+    for (int i = 0; i < 4; i++) out[k++] = gl2_sub(gl2_mul(swap, gl2_sub(lw[i + 4], lw[i])), lw[25 + i]);
+    for (int i = 0; i < 4; i++) { st[i] = gl2_add(lw[i], lw[25 + i]); st[i + 4] = gl2_sub(lw[i + 4], lw[25 + i]); }
+    for (int i = 8; i < 12; i++) st[i] = lw[i];
+    int rc = 0;
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from((u64)GL_POSEIDON_RC[rc + i]));
+        rc += 12;
+        if (r != 0) for (int i = 0; i < 12; i++) { gl2 in = lw[29 + 12 * (r - 1) + i]; out[k++] = gl2_sub(st[i], in); st[i] = in; }
+        for (int i = 0; i < 12; i++) st[i] = gl2_sbox7(st[i]);
+        gl2_mds(st);
+    }
+    for (int r = 0; r < 22; r++) {
+        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from((u64)GL_POSEIDON_RC[rc + i]));
+        rc += 12;
+        gl2 in = lw[65 + r]; out[k++] = gl2_sub(st[0], in);
+        st[0] = gl2_sbox7(in);
+        gl2_mds(st);
+    }
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 12; i++) st[i] = gl2_add(st[i], gl2_from((u64)GL_POSEIDON_RC[rc + i]));
+        rc += 12;
+        for (int i = 0; i < 12; i++) { gl2 in = lw[87 + 12 * r + i]; out[k++] = gl2_sub(st[i], in); st[i] = in; }
+        for (int i = 0; i < 12; i++) st[i] = gl2_sbox7(st[i]);
+        gl2_mds(st);
+    }
+    for (int i = 0; i < 12; i++) out[k++] = gl2_sub(st[i], lw[12 + i]);
+}
+
 static void eval_gate_unfiltered(const glo_gate *g, const gl2 *gc /* gate constants (selectors removed) */,
                                  const gl2 *lw, const u64 pih[4], gl2 *out) {
     switch (g->type) {
@@ -87,6 +136,7 @@ static void eval_gate_unfiltered(const glo_gate *g, const gl2 *gc /* gate consta
             out[i] = gl2_sub(o, comp);
         }
         break;
+    case GLO_GATE_POSEIDON: eval_poseidon_gate(lw, out); break;
     case GLO_GATE_U32_INTERLEAVE: { /* [REF src/u32/gates/interleave_u32.rs:84-135] */
         u32 k = 0;
         for (u32 i = 0; i < g->p0; i++) {

@@ -279,6 +279,47 @@ __global__ __launch_bounds__(256) void k_quotient(QArgs a) {
             }
             break;
         }
+        case GLP_GATE_POSEIDON: {
+            // gates/poseidon.rs: wires = inputs 0..11, outputs 12..23, swap 24, delta 25..28, full_sbox_0(r=1..3)
+            // from 29, partial_sbox from 65, full_sbox_1 from 87.  Naive round schedule: the S-box inputs (the
+            // only place wires enter) are identical to plonky2's sparse-matrix schedule.
+            u32 k = 0;
+            u64 st[12];
+            const u64 swap = W[(size_t)24 * N];
+            EMIT(k, mul(swap, sub(swap, 1))); k++;
+            for (u32 i = 0; i < 4; i++) {
+                const u64 lhs = W[(size_t)i * N], rhs = W[(size_t)(i + 4) * N], dl = W[(size_t)(25 + i) * N];
+                EMIT(k, sub(mul(swap, sub(rhs, lhs)), dl)); k++;
+                st[i] = add(lhs, dl); st[i + 4] = sub(rhs, dl);
+            }
+            for (u32 i = 8; i < 12; i++) st[i] = W[(size_t)i * N];
+            u32 rc = 0;
+            for (u32 r = 0; r < 4; r++) {
+                for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[rc + i]);
+                rc += 12;
+                if (r != 0)
+                    for (u32 i = 0; i < 12; i++) { const u64 in = W[(size_t)(29 + 12 * (r - 1) + i) * N]; EMIT(k, sub(st[i], in)); k++; st[i] = in; }
+                for (u32 i = 0; i < 12; i++) st[i] = pos::sbox7(st[i]);
+                pos::mds_layer(st);
+            }
+            for (u32 r = 0; r < 22; r++) {
+                for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[rc + i]);
+                rc += 12;
+                const u64 in = W[(size_t)(65 + r) * N];
+                EMIT(k, sub(st[0], in)); k++;
+                st[0] = pos::sbox7(in);
+                pos::mds_layer(st);
+            }
+            for (u32 r = 0; r < 4; r++) {
+                for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[rc + i]);
+                rc += 12;
+                for (u32 i = 0; i < 12; i++) { const u64 in = W[(size_t)(87 + 12 * r + i) * N]; EMIT(k, sub(st[i], in)); k++; st[i] = in; }
+                for (u32 i = 0; i < 12; i++) st[i] = pos::sbox7(st[i]);
+                pos::mds_layer(st);
+            }
+            for (u32 i = 0; i < 12; i++) { EMIT(k, sub(st[i], W[(size_t)(12 + i) * N])); k++; }
+            break;
+        }
         case GLP_GATE_U32_INTERLEAVE: {
             u32 k = 0;
             for (u32 i = 0; i < g.p0; i++) {
@@ -902,6 +943,7 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         const glp_gate &g = d.gates[i];
         switch (g.type) {
         case GLP_GATE_NOOP: case GLP_GATE_CONSTANT: case GLP_GATE_PUBLIC_INPUT: case GLP_GATE_ARITHMETIC:
+        case GLP_GATE_POSEIDON: if (g.type == GLP_GATE_POSEIDON && d.num_wires < 135) return set_error(GLP_ERR_ARG, "PoseidonGate needs 135 wires"); break;
         case GLP_GATE_U32_INTERLEAVE: case GLP_GATE_UNINTERLEAVE_U32: case GLP_GATE_UNINTERLEAVE_B32: break;
         default: return set_error(GLP_ERR_UNSUPPORTED, "gate type %u is not built into the quotient kernel yet", g.type);
         }

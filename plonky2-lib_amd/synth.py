@@ -26,6 +26,7 @@ _GATE_META = {
     GATE_CONSTANT: (1, "ConstantGate {{ num_consts: {p0} }}"),
     GATE_PUBLIC_INPUT: (1, "PublicInputGate"),
     GATE_ARITHMETIC: (3, "ArithmeticGate {{ num_ops: {p0} }}"),
+    GATE_POSEIDON: (7, "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"),
     GATE_U32_INTERLEAVE: (2, "U32InterleaveGate {{ num_ops: {p0} }}"),
     GATE_UNINTERLEAVE_U32: (2, "UninterleaveToU32Gate {{ num_ops: {p0} }}"),
     GATE_UNINTERLEAVE_B32: (2, "UninterleaveToB32Gate {{ num_ops: {p0} }}"),
@@ -33,7 +34,7 @@ _GATE_META = {
 
 
 def gate_num_constraints(t, p0):
-    return {GATE_NOOP: 0, GATE_CONSTANT: p0, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: p0,
+    return {GATE_NOOP: 0, GATE_CONSTANT: p0, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: p0, GATE_POSEIDON: 123,
             GATE_U32_INTERLEAVE: p0 * 34, GATE_UNINTERLEAVE_U32: p0 * 67, GATE_UNINTERLEAVE_B32: p0 * 67}[t]
 
 
@@ -282,4 +283,95 @@ def u32_circuit(log_n=6, config=None, seed=2):
         if j + 1 < num_ops:
             b.wires[4 * (j + 1) + 2, rows_a] = out
             b.connect_pairs(rows_a, 4 * j + 3, rows_a, 4 * (j + 1) + 2)
+    return b.build()
+
+
+def _fill_poseidon_row(b, row, inputs):
+    """Sets the 135 wires of a PoseidonGate row (gates/poseidon.rs layout) for `inputs` with swap = 0."""
+    from . import poseidon_py as pp
+    out, f0, part, f1 = pp.permute_trace(inputs)
+    w = b.wires
+    for i in range(12):
+        w[i, row] = inputs[i]
+        w[12 + i, row] = out[i]
+    w[24, row] = 0
+    for i in range(4):
+        w[25 + i, row] = 0
+    for r in range(3):
+        for i in range(12):
+            w[29 + 12 * r + i, row] = f0[r][i]
+    for r in range(22):
+        w[65 + r, row] = part[r]
+    for r in range(4):
+        for i in range(12):
+            w[87 + 12 * r + i, row] = f1[r][i]
+    return out
+
+
+def zkdsa_circuit(log_n=3, config=None, seed=5, private_key=None, message=None):
+    """The reference's simple-signature circuit [REF src/zkdsa/circuits/mod.rs:24-43,
+    src/zkdsa/gadgets/signature/mod.rs:49-62]: public_key = H(sk || sk), signature = H(sk || msg) with
+    `poseidon_two_to_one` [REF src/poseidon/gadgets/mod.rs:7-22]; public inputs = message, public_key,
+    signature (12 elements), whose in-circuit hash (two more permutations) feeds the PublicInputGate.
+    Rows: PublicInputGate, 4 x PoseidonGate, ConstantGate (zero), NoopGate padding -- 2^3 rows like
+    the real circuit; gate placement and wiring are this builder's, not plonky2's."""
+    cfg = config or Config.standard_recursion_config()
+    b = Builder(cfg, log_n, seed)
+    rng = b.rng
+    sk = [int(x) for x in (gl.rand(rng, 4) if private_key is None else private_key)]
+    msg = [int(x) for x in (gl.rand(rng, 4) if message is None else message)]
+    rows_p = [1, 2, 3, 4]
+    row_c = 5
+    b.set_rows(np.array([0]), GATE_PUBLIC_INPUT, 0)
+    b.set_rows(np.array(rows_p), GATE_POSEIDON, 0)
+    b.set_rows(np.array([row_c]), GATE_CONSTANT, cfg.num_constants)
+    b.gate_consts[:, row_c] = 0
+    b.wires[:cfg.num_constants, row_c] = 0
+    pk = _fill_poseidon_row(b, 1, sk + sk + [0] * 4)[:4]
+    sig = _fill_poseidon_row(b, 2, sk + msg + [0] * 4)[:4]
+    pis = msg + pk + sig
+    o3 = _fill_poseidon_row(b, 3, pis[:8] + [0] * 4)
+    o4 = _fill_poseidon_row(b, 4, pis[8:12] + o3[4:12])
+    b.public_inputs = np.array(pis, dtype=np.uint64)
+    b.wires[:4, 0] = o4[:4]
+    cyc = lambda cells: b.connect_cycle([r for r, _ in cells], [c for _, c in cells])
+    for i in range(4):
+        cyc([(1, i), (1, 4 + i), (2, i)])                 # private key
+        cyc([(2, 4 + i), (3, i)])                          # message
+        cyc([(1, 12 + i), (3, 4 + i)])                     # public key
+        cyc([(2, 12 + i), (4, i)])                         # signature
+        cyc([(4, 12 + i), (0, i)])                         # public-input hash -> PublicInputGate
+    for i in range(4, 12):
+        cyc([(3, 12 + i), (4, i)])                         # sponge state carried into the second absorb
+    zeros = [(row_c, 0)] + [(r, 24) for r in rows_p] + [(r, 8 + i) for r in (1, 2, 3) for i in range(4)]
+    cyc(zeros)                                             # constant zero: swap flags and capacity lanes
+    return b.build()
+
+
+def poseidon_chain_circuit(log_n, config=None, seed=6):
+    """SMT-shaped stand-in [REF src/smt/gadgets/verify/verify_smt.rs:214-307: a chain of Poseidon hashes
+    walking up a Merkle path]: rows 1..n-3 are PoseidonGate rows, each absorbing the previous digest."""
+    cfg = config or Config.standard_recursion_config()
+    b = Builder(cfg, log_n, seed)
+    n = b.n
+    rows_p = list(range(1, n - 2))
+    row_c = n - 2
+    b.set_rows(np.array([0]), GATE_PUBLIC_INPUT, 0)
+    b.set_rows(np.array(rows_p), GATE_POSEIDON, 0)
+    b.set_rows(np.array([row_c]), GATE_CONSTANT, cfg.num_constants)
+    b.gate_consts[:, row_c] = 0
+    b.wires[:cfg.num_constants, row_c] = 0
+    b.wires[:4, 0] = 0
+    cur = [int(x) for x in gl.rand(b.rng, 4)]
+    zeros = [(row_c, 0), (0, 0), (0, 1), (0, 2), (0, 3)]
+    prev = None
+    for r in rows_p:
+        sib = [int(x) for x in gl.rand(b.rng, 4)]
+        out = _fill_poseidon_row(b, r, cur + sib + [0] * 4)
+        if prev is not None:
+            for i in range(4):
+                b.connect_cycle([prev, r], [12 + i, i])
+        zeros += [(r, 24)] + [(r, 8 + i) for i in range(4)]
+        cur, prev = out[:4], r
+    b.connect_cycle([r for r, _ in zeros], [c for _, c in zeros])
     return b.build()

@@ -71,6 +71,23 @@ def test_prove_parity_reference_u32_gates(ctx, oracle):
     _check(ctx, oracle, desc)
 
 
+def test_prove_parity_zkdsa_circuit(ctx, oracle):
+    """BASELINE config 5: the simple-signature circuit, 2^3 rows, 4 PoseidonGate rows, 12 public inputs, two
+    selector groups (PoseidonGate has degree 7)."""
+    desc = synth.zkdsa_circuit(3)
+    assert desc.num_selectors == 2
+    # public inputs = message, public_key, signature [REF src/zkdsa/circuits/mod.rs:34-36]
+    pk = oracle.two_to_one(desc.wires[0:4, 1], desc.wires[4:8, 1])
+    assert (desc.public_inputs[4:8] == pk).all()
+    oc, gc, got = _check(ctx, oracle, desc)
+    assert (got[-12:] == desc.public_inputs).all()
+
+
+def test_prove_parity_poseidon_chain(ctx, oracle):
+    """BASELINE config 4 shape: a 2^5-row chain of PoseidonGate rows (SMT path walk)."""
+    _check(ctx, oracle, synth.poseidon_chain_circuit(5))
+
+
 def test_unsatisfied_witness_fails_verification(ctx, oracle):
     desc = synth.arith_circuit(7, seed=11)
     oc = oracle.OracleCircuit(desc)
@@ -98,7 +115,7 @@ def test_prove_properties_2_16(ctx, oracle):
 
 def test_unsupported_gate_is_reported(ctx):
     desc = synth.arith_circuit(5, seed=1)
-    desc.gates[0]["type"] = 4          # PoseidonGate: not in the quotient kernel yet
+    desc.gates[0]["type"] = 99         # not a gate this build knows
     with pytest.raises(glp.GlpError) as e:
         glp.Circuit(ctx, desc)
     assert e.value.code == -3

@@ -61,6 +61,30 @@ def test_reference_u32_gates(oracle):
     assert oc.verify(p2) != 0
 
 
+def test_zkdsa_circuit(oracle):
+    """The reference's simple-signature relation [REF src/zkdsa/gadgets/signature/mod.rs:49-62]: default
+    inputs reproduce the reference's known-answer public key [REF src/zkdsa/circuits/mod.rs:85-101]."""
+    c = synth.zkdsa_circuit(3, private_key=[0, 0, 0, 0], message=[0, 0, 0, 0])
+    kat = [4330397376401421145, 14124799381142128323, 8742572140681234676, 14345658006221440202]
+    assert [int(x) for x in c.public_inputs] == [0, 0, 0, 0] + kat + kat
+    assert c.num_selectors == 2 and c.num_gate_constraints == 123
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    w = c.wires.copy(); w[70, 2] = np.uint64((int(w[70, 2]) + 1) % oracle.P)     # a partial-round S-box wire
+    rc, bad = oc.prove(wires=w)
+    assert oc.verify(bad) != 0
+    bad = proof.copy(); bad[-1] = np.uint64((int(bad[-1]) + 1) % oracle.P)       # claim a different signature
+    assert oc.verify(bad) != 0
+
+
+def test_poseidon_chain_circuit(oracle):
+    c = synth.poseidon_chain_circuit(4)
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+
+
 def test_fri_reduction_schedule():
     cfg = synth.Config.standard_ecc_config()
     assert cfg.reduction_arity_bits(20) == [4, 4, 4, 4]       # SURVEY section 8: final polynomial of 16 coefficients

@@ -53,6 +53,22 @@ def pmc_traffic(stage_key, log_n):
     return max(r["hbm_bytes"] for r in rows) if rows else None
 
 
+def valu_roofline(stage_key, ms, log_n, ncols):
+    """Integer-issue roofline of the Poseidon leaf kernel: issue slots per permutation come from the
+    emitted ISA (profiles/isa_slots.py -> profiles/r01_poseidon_isa_slots.json; half-rate instructions
+    count 2), peak = 256 CUs x 128 lanes/clk x 2.4 GHz (nominal clock; the chip sustains less under
+    this load, see profiles/r01_ubench_int_issue*.txt)."""
+    path = os.path.join(ROOT, "profiles", "r01_poseidon_isa_slots.json")
+    if not stage_key.endswith("merkle_leaves") or not os.path.exists(path):
+        return None
+    slots = json.load(open(path))["slots_per_permutation"]
+    perms = (1 << (log_n + 3)) * ((ncols + 7) // 8)
+    ach = perms * slots / (ms / 1e3)
+    peak = 256 * 128 * 2.4e9
+    return {"bound": "valu-int", "permutations": perms, "issue_slots_per_permutation": slots,
+            "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "T lane-ops/s", "frac": ach / peak}
+
+
 def cpu_baseline(sample_log_n, full_log_n):
     """Times the oracle (CPU restatement of plonky2's prove(), kind="port") on a bounded sample of the
     same workload: the same synthetic ECDSA-shaped circuit with 2^sample_log_n rows.  Commit stages
@@ -182,6 +198,7 @@ def main():
                 "ntt_plus_merkle": {"alg_GB": round(nm_bytes / 1e9, 3), "ms": round(nm_ms, 3),
                                     "GBps": round(nm_bytes / 1e9 / (nm_ms / 1e3), 1),
                                     "frac": round(nm_bytes / 1e9 / (nm_ms / 1e3) / HBM_PEAK_GBS, 4)},
+                "valu": valu_roofline(dom, stage_out[dom]["ms"], lg, dict(SHAPES).get(dom.split("/")[0], 0)),
                 "gpu_stage_ms_sum": round(gpu_ms, 3),
                 "stages": stage_out,
             },

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Issue-slot count of one Poseidon permutation, from the gfx950 ISA hipcc emits for csrc/merkle.hip.
+A slot = one full-rate VALU wave-instruction (2 cycles on a SIMD-32); v_mad_u64_u32, v_mul_{lo,hi}_u32,
+v_lshl_add_u64 and 64-bit shifts issue at half rate on gfx950 (profiles/r01_ubench_int_issue.txt) and
+count 2.  The permutation is three loops: 4 full rounds, 22 partial rounds, 4 full rounds; per-loop
+bodies are recognised by their multiply count.  Prints JSON."""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HALF = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshlrev_b64", "v_lshrrev_b64", "v_mad_i64_i32"}
+
+
+def main():
+    src = os.path.join(ROOT, "plonky2-lib_amd", "csrc", "merkle.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "merkle.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-o", out, src], stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+    body = txt[txt.index("_ZN3glp16k_permute_statesEPmm:"):]
+    body = body[:body.index("s_endpgm")]
+    blocks, cur = [], []
+    for l in body.split("\n"):
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            blocks.append(cur); cur = []
+        else:
+            m = re.match(r"^\s+([vs]_\w+|ds_\w+|global_\w+)", l)
+            if m:
+                cur.append(m.group(1))
+    blocks.append(cur)
+    res = []
+    for b in blocks:
+        c = collections.Counter(b)
+        mads = c["v_mad_u64_u32"]
+        if mads < 100:
+            continue
+        valu = sum(v for k, v in c.items() if k.startswith("v_"))
+        slots = sum(v * (2 if k in HALF else 1) for k, v in c.items() if k.startswith("v_"))
+        res.append({"mads": mads, "valu_instructions": valu, "issue_slots": slots, "s_nop": c["s_nop"]})
+    full = [r for r in res if 400 <= r["mads"] <= 470]
+    part = [r for r in res if 200 <= r["mads"] <= 300]
+    per_full = min(r["issue_slots"] for r in full) if full else None
+    per_part = min(r["issue_slots"] for r in part) if part else None
+    out = {"loop_bodies": res, "full_round_slots": per_full, "partial_round_slots": per_part,
+           "slots_per_permutation": (8 * per_full + 22 * per_part) if per_full and per_part else None}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,16 @@ GLP_API int glp_prove(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *
 GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *dev_wires,
                              const uint64_t *public_inputs, uint64_t *proof_out);
 
+/* plonky2 `ProofWithPublicInputs::to_bytes()` (util/serialization.rs `Buffer::write_proof_with_public_inputs`):
+ * every field element as 8 little-endian bytes in the word order above, plus the one-byte sibling
+ * count that `write_merkle_proof` puts in front of every Merkle path.  This is the wire format the
+ * reference round-trips at [REF src/ecdsa/gadgets/ecdsa.rs:298-316] for circuits and that a Rust
+ * `ProofWithPublicInputs::from_bytes(bytes, &data.common)` consumes.  (Recalled format: not pinned by
+ * a fixture, see DESIGN.md.) */
+GLP_API size_t glp_proof_bytes_len(const glp_circuit *circuit);
+GLP_API int glp_proof_to_bytes(const glp_circuit *circuit, const uint64_t *proof_words, uint8_t *bytes_out, size_t bytes_len);
+GLP_API int glp_proof_from_bytes(const glp_circuit *circuit, const uint8_t *bytes, size_t bytes_len, uint64_t *proof_words_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,12 +101,16 @@ def load_library():
     }
     L.glp_proof_words.restype = sz
     L.glp_proof_words.argtypes = [vp]
+    L.glp_proof_bytes_len.restype = sz
+    L.glp_proof_bytes_len.argtypes = [vp]
     sigs.update({
         "glp_circuit_create": [vp, C.POINTER(_CircuitDesc), C.POINTER(vp)],
         "glp_circuit_free": [vp],
         "glp_circuit_digest": [vp, vp],
         "glp_circuit_constants_sigmas_cap": [vp, vp],
         "glp_prove": [vp, vp, vp, vp, vp],
+        "glp_proof_to_bytes": [vp, vp, vp, sz],
+        "glp_proof_from_bytes": [vp, vp, sz, vp],
         "glp_prove_device": [vp, vp, vp, vp, vp],
     })
     for name, argtypes in sigs.items():
@@ -358,6 +362,20 @@ class Circuit:
         proof = np.zeros(self.proof_words, np.uint64)
         _chk(load_library().glp_prove(self.ctx._h, self._h, _p(w), _p(pi) if pi.size else None, _p(proof)))
         return proof
+
+    def proof_to_bytes(self, proof_words):
+        """`ProofWithPublicInputs::to_bytes()`."""
+        L = load_library()
+        n = L.glp_proof_bytes_len(self._h)
+        out = np.empty(n, np.uint8)
+        _chk(L.glp_proof_to_bytes(self._h, _p(_a(proof_words)), out.ctypes.data_as(C.c_void_p), n))
+        return out.tobytes()
+
+    def proof_from_bytes(self, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        words = np.zeros(self.proof_words, np.uint64)
+        _chk(load_library().glp_proof_from_bytes(self._h, buf.ctypes.data_as(C.c_void_p), buf.size, _p(words)))
+        return words
 
     def prove_device(self, dev_wires_ptr, public_inputs=None):
         pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)

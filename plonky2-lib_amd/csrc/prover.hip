@@ -901,6 +901,30 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
     return GLP_OK;
 }
 
+// ---- byte format (util/serialization.rs): words little-endian, u8 sibling count before each Merkle path
+namespace {
+// calls f(offset_words, count_words, is_path_start) for the pieces of a proof in order
+template <class F> void walk_proof(const glp_circuit *cc, F f) {
+    const Layout &L = cc->L;
+    const glp_circuit_desc &d = cc->d;
+    f((size_t)0, L.queries, false);                     // caps, openings, commit-phase caps
+    for (u32 q = 0; q < d.num_query_rounds; q++) {
+        size_t o = L.queries + (size_t)q * L.query_stride;
+        for (int k = 0; k < 4; k++) {
+            f(o, (size_t)L.oracle_cols[k], false); o += L.oracle_cols[k];
+            f(o, 4 * (size_t)L.depth0, true); o += 4 * (size_t)L.depth0;
+        }
+        for (u32 r = 0; r < d.num_reductions; r++) {
+            const size_t ev = (size_t)2 << d.reduction_arity_bits[r];
+            f(o, ev, false); o += ev;
+            f(o, 4 * (size_t)L.step_depth[r], true); o += 4 * (size_t)L.step_depth[r];
+        }
+    }
+    f(L.final_poly, L.total - L.final_poly, false);     // final poly, pow witness, public inputs
+}
+}  // namespace
+
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -1012,6 +1036,46 @@ int glp_circuit_constants_sigmas_cap(const glp_circuit *cc, uint64_t *cap_out) {
     return GLP_OK;
 }
 size_t glp_proof_words(const glp_circuit *cc) { return cc ? cc->L.total : 0; }
+
+size_t glp_proof_bytes_len(const glp_circuit *cc) {
+    if (!cc) return 0;
+    size_t paths = 0;
+    walk_proof(cc, [&](size_t, size_t, bool path) { paths += path ? 1 : 0; });
+    return cc->L.total * 8 + paths;
+}
+
+int glp_proof_to_bytes(const glp_circuit *cc, const uint64_t *words, uint8_t *out, size_t len) {
+    GLP_REQUIRE(cc && words && out, "null argument");
+    GLP_REQUIRE(len == glp_proof_bytes_len(cc), "bytes_len must equal glp_proof_bytes_len()");
+    size_t o = 0;
+    walk_proof(cc, [&](size_t off, size_t cnt, bool path) {
+        if (path) out[o++] = (uint8_t)(cnt / 4);
+        for (size_t i = 0; i < cnt; i++) {
+            const u64 w = words[off + i];
+            for (int b = 0; b < 8; b++) out[o++] = (uint8_t)(w >> (8 * b));
+        }
+    });
+    return GLP_OK;
+}
+
+int glp_proof_from_bytes(const glp_circuit *cc, const uint8_t *in, size_t len, uint64_t *words) {
+    GLP_REQUIRE(cc && words && in, "null argument");
+    GLP_REQUIRE(len == glp_proof_bytes_len(cc), "byte length does not match this circuit");
+    size_t o = 0;
+    int bad = 0;
+    walk_proof(cc, [&](size_t off, size_t cnt, bool path) {
+        if (path && in[o++] != (uint8_t)(cnt / 4)) bad = 1;
+        for (size_t i = 0; i < cnt; i++) {
+            u64 w = 0;
+            for (int b = 0; b < 8; b++) w |= (u64)in[o++] << (8 * b);
+            if (w >= glf::P) bad = 2;
+            words[off + i] = w;
+        }
+    });
+    if (bad == 1) return set_error(GLP_ERR_ARG, "Merkle path length byte does not match the circuit's FRI parameters");
+    if (bad == 2) return set_error(GLP_ERR_ARG, "non-canonical field element in proof bytes");
+    return GLP_OK;
+}
 
 int glp_prove_device(glp_ctx *c, const glp_circuit *cc, const uint64_t *dev_wires, const uint64_t *public_inputs, uint64_t *proof_out) {
     GLP_REQUIRE(c && cc && dev_wires && proof_out, "null argument");

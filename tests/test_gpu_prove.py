@@ -113,6 +113,28 @@ def test_prove_properties_2_16(ctx, oracle):
     assert oc.verify(bad) != 0
 
 
+def test_proof_bytes_roundtrip(ctx, oracle):
+    desc = synth.arith_circuit(9, seed=21)
+    gc = glp.Circuit(ctx, desc)
+    words = gc.prove()
+    data = gc.proof_to_bytes(words)
+    depth0 = desc.degree_bits + desc.rate_bits - desc.cap_height
+    n_paths = desc.num_query_rounds * (4 + len(desc.reduction_arity_bits))
+    assert len(data) == 8 * len(words) + n_paths
+    assert data[:8] == int(words[0]).to_bytes(8, "little")
+    # first Merkle path of the first query: one length byte, then depth0 digests
+    nch = desc.num_challenges
+    nopen = (desc.num_constants + desc.num_routed_wires + desc.num_wires + 2 * nch + nch * desc.num_partial_products +
+             nch * desc.quotient_degree_factor)
+    cap = 4 << desc.cap_height
+    q0 = 8 * (3 * cap + 2 * nopen + cap * len(desc.reduction_arity_bits)) + 8 * (desc.num_constants + desc.num_routed_wires)
+    assert data[q0] == depth0
+    assert (gc.proof_from_bytes(data) == words).all()
+    bad = bytearray(data); bad[q0] ^= 1
+    with pytest.raises(glp.GlpError):
+        gc.proof_from_bytes(bytes(bad))
+
+
 def test_unsupported_gate_is_reported(ctx):
     desc = synth.arith_circuit(5, seed=1)
     desc.gates[0]["type"] = 99         # not a gate this build knows

@@ -60,11 +60,16 @@ GLF_HD void mul128(u64 a, u64 b, u64& lo, u64& hi) {
     lo = (u64)p; hi = (u64)(p >> 64);
 #endif
 }
+__device__ __forceinline__ u64 mul_nc(u64 a, u64 b);
 // any u64 inputs -> canonical
 GLF_HD u64 mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return canon(mul_nc(a, b));      // 32-bit limb form: fewer issue slots on gfx950 than 64-bit compare + select
+#else
     u64 lo, hi;
     mul128(a, b, lo, hi);
     return reduce128(lo, hi);
+#endif
 }
 GLF_HD u64 sqr(u64 a) { return mul(a, a); }
 

@@ -411,10 +411,16 @@ __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ co
     const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(coeffs + (size_t)col * n + (size_t)pb * B + 16 * tid);
     __syncthreads();
     const int hi4 = tid >> 4, lo4 = tid & 15;
-    const int kb1 = brev4(lo4);          // step 1: rb = lo4
-    const int kc2 = brev4(lo4);          // step 2: rc = lo4, qa = hi4
+    const int kb1_ = brev4(lo4);         // step 1: rb = lo4
+    const int kc2_ = brev4(lo4);         // step 2: rc = lo4, qa = hi4
     for (int r = 0; r < R; r++) {
         u64 x[16];
+#ifdef GLP_LDE_NO_HOIST
+        int kb1 = kb1_, kc2 = kc2_;
+        asm volatile("" : "+v"(kb1), "+v"(kc2));      // keep twiddle loads inside the loop (register pressure)
+#else
+        const int kb1 = kb1_, kc2 = kc2_;
+#endif
         {
             const ulonglong2 *pr = reinterpret_cast<const ulonglong2 *>(pre + (size_t)r * B + 16 * tid);
 #pragma unroll

@@ -77,7 +77,7 @@ def cpu_baseline(sample_log_n, full_log_n):
     import plonky2_lib_amd.synth as synth
     oracle.build()
     cores = oracle.max_threads()
-    desc = synth.arith_circuit(sample_log_n, synth.Config.standard_ecc_config(), seed=SEED)
+    desc = synth.ecdsa_shape_circuit(sample_log_n, seed=SEED)
     oc = oracle.OracleCircuit(desc)
     t0 = time.perf_counter()
     rc, proof = oc.prove()
@@ -108,7 +108,7 @@ def main():
     ctx = glp.Context(local_rank)
     # One independent proof per rank: same circuit, rank-specific witness seed.  Circuit construction
     # (the reference's `builder.build()`) and witness generation are CPU work outside the timed region.
-    desc = synth.arith_circuit(lg, synth.Config.standard_ecc_config(), seed=SEED + 1000 * rank)
+    desc = synth.ecdsa_shape_circuit(lg, seed=SEED + 1000 * rank)
     circuit = glp.Circuit(ctx, desc)
     wires = torch.from_numpy(desc.wires.view(np.int64)).to(dev)     # HBM resident before timing starts
     desc.constants = desc.sigmas = None
@@ -176,11 +176,13 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "ECDSA-verify-shaped circuit (standard_ecc_config: 2^%d rows x 136 wires, 80 routed, 2 challenges, "
-                            "rate_bits 3, cap_height 4, 28 FRI queries, 16 PoW bits; ArithmeticGate/ConstantGate/"
-                            "PublicInputGate/NoopGate rows with copy constraints); one full prove() per step from an HBM-"
-                            "resident witness: wires commit, partial products, quotient, openings, FRI, PoW, queries" % lg,
-                "note": "the real secp256k1 circuit needs the Rust builder (absent); its gate set (U32/BaseSum/RandomAccess/"
-                        "Comparison gates) costs more in the quotient stage than this stand-in's ArithmeticGate rows",
+                            "rate_bits 3, cap_height 4, 28 FRI queries, 16 PoW bits; all 11 gate types the reference registers for "
+                            "its secp256k1 circuit -- Arithmetic, BaseSum<4>, Comparison, Constant, RandomAccess(4), U32Arithmetic, "
+                            "U32AddMany, U32RangeCheck, U32Subtraction, PublicInput, Noop -- in 3 selector groups, copy constraints); "
+                            "one full prove() per step from an HBM-resident witness: wires commit, partial products, quotient, "
+                            "openings, FRI, PoW, queries" % lg,
+                "note": "the real circuit needs the Rust builder (absent): same shape and constraint set per point, synthetic "
+                        "row mix (ArithmeticGate rows fill the trace) and wiring",
                 "parallelism": "independent proofs sharded one per GPU, no collective",
             },
             "roofline": {

@@ -122,7 +122,16 @@ enum {
     GLP_GATE_POSEIDON = 4,         /* gates/poseidon.rs */
     GLP_GATE_U32_INTERLEAVE = 5,   /* [REF src/u32/gates/interleave_u32.rs:33-82,84-135], p0 = num_ops */
     GLP_GATE_UNINTERLEAVE_U32 = 6, /* [REF src/u32/gates/uninterleave_to_u32.rs:30-91,93-150], p0 = num_ops */
-    GLP_GATE_UNINTERLEAVE_B32 = 7  /* [REF src/u32/gates/uninterleave_to_b32.rs:95-150], p0 = num_ops */
+    GLP_GATE_UNINTERLEAVE_B32 = 7, /* [REF src/u32/gates/uninterleave_to_b32.rs:95-150], p0 = num_ops */
+    /* the gate set of the secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96]; sources absent from the
+     * reference (plonky2, plonky2_u32 @552acaec [REF Cargo.lock:1001-1009]), restated from the published crates */
+    GLP_GATE_U32_ARITHMETIC = 8,   /* plonky2_u32 gates/arithmetic_u32.rs, p0 = num_ops */
+    GLP_GATE_U32_ADD_MANY = 9,     /* plonky2_u32 gates/add_many_u32.rs, p0 = num_addends, p1 = num_ops */
+    GLP_GATE_U32_SUBTRACTION = 10, /* plonky2_u32 gates/subtraction_u32.rs, p0 = num_ops */
+    GLP_GATE_U32_RANGE_CHECK = 11, /* plonky2_u32 gates/range_check_u32.rs, p0 = num_input_limbs */
+    GLP_GATE_COMPARISON = 12,      /* plonky2_u32 gates/comparison.rs, p0 = num_bits, p1 = num_chunks */
+    GLP_GATE_BASE_SUM = 13,        /* plonky2 gates/base_sum.rs, p0 = num_limbs, p1 = base */
+    GLP_GATE_RANDOM_ACCESS = 14    /* plonky2 gates/random_access.rs, p0 = bits, p1 = num_copies | num_extra_constants << 16 */
 };
 
 typedef struct {

@@ -18,6 +18,15 @@ enum {
     GLO_GATE_U32_INTERLEAVE = 5,      /* [REF src/u32/gates/interleave_u32.rs:33-82,230-266]   p0 = num_ops */
     GLO_GATE_UNINTERLEAVE_U32 = 6,    /* [REF src/u32/gates/uninterleave_to_u32.rs:30-91,262-309] p0 = num_ops */
     GLO_GATE_UNINTERLEAVE_B32 = 7,    /* [REF src/u32/gates/uninterleave_to_b32.rs] p0 = num_ops */
+    /* gates of the secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96 lists them for its serializer];
+     * their sources (plonky2, plonky2_u32 @552acaec) are absent: restated from the published crates */
+    GLO_GATE_U32_ARITHMETIC = 8,      /* plonky2_u32 gates/arithmetic_u32.rs   p0 = num_ops */
+    GLO_GATE_U32_ADD_MANY = 9,        /* plonky2_u32 gates/add_many_u32.rs     p0 = num_addends, p1 = num_ops */
+    GLO_GATE_U32_SUBTRACTION = 10,    /* plonky2_u32 gates/subtraction_u32.rs  p0 = num_ops */
+    GLO_GATE_U32_RANGE_CHECK = 11,    /* plonky2_u32 gates/range_check_u32.rs  p0 = num_input_limbs */
+    GLO_GATE_COMPARISON = 12,         /* plonky2_u32 gates/comparison.rs       p0 = num_bits, p1 = num_chunks */
+    GLO_GATE_BASE_SUM = 13,           /* plonky2 gates/base_sum.rs             p0 = num_limbs, p1 = base */
+    GLO_GATE_RANDOM_ACCESS = 14,      /* plonky2 gates/random_access.rs        p0 = bits, p1 = num_copies | num_extra_constants << 16 */
 };
 
 typedef struct {

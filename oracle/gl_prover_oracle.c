@@ -119,6 +119,11 @@ static void eval_poseidon_gate(const gl2 *lw, gl2 *out) {
     for (int i = 0; i < 12; i++) out[k++] = gl2_sub(st[i], lw[12 + i]);
 }
 
+static gl2 range_product(gl2 v, u32 bound) { /* prod_{x < bound} (v - x) */
+    gl2 p = gl2_from(1);
+    for (u32 x = 0; x < bound; x++) p = gl2_mul(p, gl2_sub(v, gl2_from(x)));
+    return p;
+}
 static void eval_gate_unfiltered(const glo_gate *g, const gl2 *gc /* gate constants (selectors removed) */,
                                  const gl2 *lw, const u64 pih[4], gl2 *out) {
     switch (g->type) {
@@ -171,6 +176,123 @@ static void eval_gate_unfiltered(const glo_gate *g, const gl2 *gc /* gate consta
             out[k++] = gl2_sub(co, xo);
             for (int b = 0; b < 64; b++) out[k++] = gl2_mul(bits[b], gl2_sub(bits[b], gl2_from(1)));
         }
+        break;
+    }
+    case GLO_GATE_U32_ARITHMETIC: { /* wires per op: m0, m1, addend, out_lo, out_hi, inverse; then 32 2-bit limbs per op */
+        u32 k = 0; const u32 n = g->p0;
+        for (u32 i = 0; i < n; i++) {
+            gl2 m0 = lw[6 * i], m1 = lw[6 * i + 1], ad = lw[6 * i + 2], lo = lw[6 * i + 3], hi = lw[6 * i + 4], inv = lw[6 * i + 5];
+            gl2 computed = gl2_add(gl2_mul(m0, m1), ad);
+            gl2 diff = gl2_sub(gl2_from(0xFFFFFFFFull), hi);
+            gl2 hi_not_max = gl2_sub(gl2_mul(inv, diff), gl2_from(1));
+            out[k++] = gl2_mul(hi_not_max, lo);
+            out[k++] = gl2_sub(gl2_add(gl2_scale(hi, (u64)1 << 32), lo), computed);
+            gl2 cl = gl2_from(0), ch = gl2_from(0);
+            const gl2 *limbs = lw + 6 * n + 32 * i;
+            for (int j = 31; j >= 0; j--) {
+                out[k++] = range_product(limbs[j], 4);
+                if (j < 16) cl = gl2_add(gl2_scale(cl, 4), limbs[j]); else ch = gl2_add(gl2_scale(ch, 4), limbs[j]);
+            }
+            out[k++] = gl2_sub(cl, lo);
+            out[k++] = gl2_sub(ch, hi);
+        }
+        break;
+    }
+    case GLO_GATE_U32_ADD_MANY: { /* per op: addends[na], carry_in, out_result, out_carry; then 16 + 2 2-bit limbs per op */
+        u32 k = 0; const u32 na = g->p0, n = g->p1, w = na + 3;
+        for (u32 i = 0; i < n; i++) {
+            gl2 sum = lw[w * i + na];
+            for (u32 j = 0; j < na; j++) sum = gl2_add(sum, lw[w * i + j]);
+            gl2 res = lw[w * i + na + 1], car = lw[w * i + na + 2];
+            out[k++] = gl2_sub(gl2_add(gl2_scale(car, (u64)1 << 32), res), sum);
+            gl2 cr = gl2_from(0), cc = gl2_from(0);
+            const gl2 *limbs = lw + w * n + 18 * i;
+            for (int j = 17; j >= 0; j--) {
+                out[k++] = range_product(limbs[j], 4);
+                if (j < 16) cr = gl2_add(gl2_scale(cr, 4), limbs[j]); else cc = gl2_add(gl2_scale(cc, 4), limbs[j]);
+            }
+            out[k++] = gl2_sub(cr, res);
+            out[k++] = gl2_sub(cc, car);
+        }
+        break;
+    }
+    case GLO_GATE_U32_SUBTRACTION: { /* per op: x, y, borrow_in, out_result, out_borrow; then 16 2-bit limbs per op */
+        u32 k = 0; const u32 n = g->p0;
+        for (u32 i = 0; i < n; i++) {
+            gl2 x = lw[5 * i], y = lw[5 * i + 1], bi = lw[5 * i + 2], res = lw[5 * i + 3], bo = lw[5 * i + 4];
+            gl2 init = gl2_sub(gl2_sub(x, y), bi);
+            out[k++] = gl2_sub(res, gl2_add(init, gl2_scale(bo, (u64)1 << 32)));
+            gl2 cl = gl2_from(0);
+            const gl2 *limbs = lw + 5 * n + 16 * i;
+            for (int j = 15; j >= 0; j--) { out[k++] = range_product(limbs[j], 4); cl = gl2_add(gl2_scale(cl, 4), limbs[j]); }
+            out[k++] = gl2_sub(cl, res);
+            out[k++] = gl2_mul(bo, gl2_sub(gl2_from(1), bo));
+        }
+        break;
+    }
+    case GLO_GATE_U32_RANGE_CHECK: { /* input limbs 0..n-1, then 16 base-4 aux limbs per input (little-endian) */
+        u32 k = 0; const u32 n = g->p0;
+        for (u32 i = 0; i < n; i++) {
+            const gl2 *aux = lw + n + 16 * i;
+            gl2 sum = gl2_from(0);
+            for (int j = 15; j >= 0; j--) sum = gl2_add(gl2_scale(sum, 4), aux[j]);
+            out[k++] = gl2_sub(sum, lw[i]);
+            for (int j = 0; j < 16; j++) out[k++] = range_product(aux[j], 4);
+        }
+        break;
+    }
+    case GLO_GATE_COMPARISON: { /* wires: first, second, result_bool, msd, chunks a[nc], b[nc], eq_dummy[nc], chunks_equal[nc], intermediate[nc], msd bits[cb+1] */
+        u32 k = 0; const u32 nb = g->p0, nc = g->p1, cb = (nb + nc - 1) / nc, cs = 1u << cb;
+        const gl2 *a = lw + 4, *b = a + nc, *ed = b + nc, *ce = ed + nc, *iv = ce + nc, *mb = iv + nc;
+        gl2 ca = gl2_from(0), cbv = gl2_from(0);
+        for (int i = (int)nc - 1; i >= 0; i--) { ca = gl2_add(gl2_scale(ca, cs), a[i]); cbv = gl2_add(gl2_scale(cbv, cs), b[i]); }
+        out[k++] = gl2_sub(ca, lw[0]);
+        out[k++] = gl2_sub(cbv, lw[1]);
+        gl2 msd = gl2_from(0);
+        for (u32 i = 0; i < nc; i++) {
+            out[k++] = range_product(a[i], cs);
+            out[k++] = range_product(b[i], cs);
+            gl2 diff = gl2_sub(b[i], a[i]);
+            out[k++] = gl2_sub(gl2_mul(diff, ed[i]), gl2_sub(gl2_from(1), ce[i]));
+            out[k++] = gl2_mul(ce[i], diff);
+            out[k++] = gl2_sub(iv[i], gl2_mul(ce[i], msd));
+            msd = gl2_add(iv[i], gl2_mul(gl2_sub(gl2_from(1), ce[i]), diff));
+        }
+        out[k++] = gl2_sub(lw[3], msd);
+        gl2 bc = gl2_from(0);
+        for (u32 j = 0; j <= cb; j++) out[k++] = gl2_mul(mb[j], gl2_sub(gl2_from(1), mb[j]));
+        for (int j = (int)cb; j >= 0; j--) bc = gl2_add(gl2_scale(bc, 2), mb[j]);
+        out[k++] = gl2_sub(gl2_add(gl2_from(cs), lw[3]), bc);
+        out[k++] = gl2_sub(lw[2], mb[cb]);
+        break;
+    }
+    case GLO_GATE_BASE_SUM: { /* wire 0 = sum, limbs 1..num_limbs little-endian in base p1 */
+        u32 k = 0; const u32 nl = g->p0, B = g->p1;
+        gl2 sum = gl2_from(0);
+        for (int j = (int)nl - 1; j >= 0; j--) sum = gl2_add(gl2_scale(sum, B), lw[1 + j]);
+        out[k++] = gl2_sub(sum, lw[0]);
+        for (u32 j = 0; j < nl; j++) out[k++] = range_product(lw[1 + j], B);
+        break;
+    }
+    case GLO_GATE_RANDOM_ACCESS: { /* per copy: access_index, claimed, list[2^bits]; extra constants; then bits per copy */
+        u32 k = 0; const u32 bits = g->p0, copies = g->p1 & 0xFFFF, nextra = g->p1 >> 16, vs = 1u << bits;
+        const u32 routed = (2 + vs) * copies + nextra;
+        for (u32 c = 0; c < copies; c++) {
+            const gl2 *base = lw + (2 + vs) * c, *bw = lw + routed + bits * c;
+            gl2 list[64];
+            for (u32 j = 0; j < vs; j++) list[j] = base[2 + j];
+            gl2 idx = gl2_from(0);
+            for (u32 b = 0; b < bits; b++) out[k++] = gl2_mul(bw[b], gl2_sub(bw[b], gl2_from(1)));
+            for (int b = (int)bits - 1; b >= 0; b--) idx = gl2_add(gl2_scale(idx, 2), bw[b]);
+            out[k++] = gl2_sub(idx, base[0]);
+            u32 len = vs;
+            for (u32 b = 0; b < bits; b++) {
+                for (u32 j = 0; j < len / 2; j++) list[j] = gl2_add(list[2 * j], gl2_mul(bw[b], gl2_sub(list[2 * j + 1], list[2 * j])));
+                len /= 2;
+            }
+            out[k++] = gl2_sub(list[0], base[1]);
+        }
+        for (u32 e = 0; e < nextra; e++) out[k++] = gl2_sub(gc[e], lw[(2 + vs) * copies + e]);
         break;
     }
     default: break;

@@ -198,6 +198,12 @@ __global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 l
     }
 }
 
+__device__ __forceinline__ u64 range_product(u64 v, u32 bound) {   // prod_{x < bound} (v - x)
+    u64 p = v;
+    for (u32 x = 1; x < bound; x++) p = mul(p, sub(v, (u64)x));
+    return p;
+}
+
 struct QArgs {
     const u64 *cs, *wl, *zl;        // coset-major LDEs [ncols][R][n]
     u64 *out;                       // [nch][Rq][n]
@@ -360,6 +366,128 @@ __global__ __launch_bounds__(256) void k_quotient(QArgs a) {
                 EMIT(k + 2, sub(co, xo));
                 k += 67;
             }
+            break;
+        }
+        case GLP_GATE_U32_ARITHMETIC: {
+            u32 k = 0; const u32 nops = g.p0;
+            for (u32 i = 0; i < nops; i++) {
+                const u64 m0 = W[(size_t)(6 * i) * N], m1 = W[(size_t)(6 * i + 1) * N], ad = W[(size_t)(6 * i + 2) * N];
+                const u64 lo = W[(size_t)(6 * i + 3) * N], hi = W[(size_t)(6 * i + 4) * N], iv = W[(size_t)(6 * i + 5) * N];
+                const u64 hi_not_max = sub(mul(iv, sub(0xFFFFFFFFull, hi)), 1);
+                EMIT(k, mul(hi_not_max, lo)); k++;
+                EMIT(k, sub(add(mul(hi, (u64)1 << 32), lo), add(mul(m0, m1), ad))); k++;
+                u64 cl = 0, chh = 0;
+                const u64 *limbs = W + (size_t)(6 * nops + 32 * i) * N;
+                for (int j = 31; j >= 0; j--) {
+                    const u64 l = limbs[(size_t)j * N];
+                    EMIT(k, range_product(l, 4)); k++;
+                    if (j < 16) cl = add(dbl(dbl(cl)), l); else chh = add(dbl(dbl(chh)), l);
+                }
+                EMIT(k, sub(cl, lo)); k++;
+                EMIT(k, sub(chh, hi)); k++;
+            }
+            break;
+        }
+        case GLP_GATE_U32_ADD_MANY: {
+            u32 k = 0; const u32 na = g.p0, nops = g.p1, wd = na + 3;
+            for (u32 i = 0; i < nops; i++) {
+                u64 sum = W[(size_t)(wd * i + na) * N];
+                for (u32 j = 0; j < na; j++) sum = add(sum, W[(size_t)(wd * i + j) * N]);
+                const u64 res = W[(size_t)(wd * i + na + 1) * N], car = W[(size_t)(wd * i + na + 2) * N];
+                EMIT(k, sub(add(mul(car, (u64)1 << 32), res), sum)); k++;
+                u64 cr = 0, cc = 0;
+                const u64 *limbs = W + (size_t)(wd * nops + 18 * i) * N;
+                for (int j = 17; j >= 0; j--) {
+                    const u64 l = limbs[(size_t)j * N];
+                    EMIT(k, range_product(l, 4)); k++;
+                    if (j < 16) cr = add(dbl(dbl(cr)), l); else cc = add(dbl(dbl(cc)), l);
+                }
+                EMIT(k, sub(cr, res)); k++;
+                EMIT(k, sub(cc, car)); k++;
+            }
+            break;
+        }
+        case GLP_GATE_U32_SUBTRACTION: {
+            u32 k = 0; const u32 nops = g.p0;
+            for (u32 i = 0; i < nops; i++) {
+                const u64 xx = W[(size_t)(5 * i) * N], yy = W[(size_t)(5 * i + 1) * N], bi = W[(size_t)(5 * i + 2) * N];
+                const u64 res = W[(size_t)(5 * i + 3) * N], bo = W[(size_t)(5 * i + 4) * N];
+                EMIT(k, sub(res, add(sub(sub(xx, yy), bi), mul(bo, (u64)1 << 32)))); k++;
+                u64 cl = 0;
+                const u64 *limbs = W + (size_t)(5 * nops + 16 * i) * N;
+                for (int j = 15; j >= 0; j--) { const u64 l = limbs[(size_t)j * N]; EMIT(k, range_product(l, 4)); k++; cl = add(dbl(dbl(cl)), l); }
+                EMIT(k, sub(cl, res)); k++;
+                EMIT(k, mul(bo, sub(1, bo))); k++;
+            }
+            break;
+        }
+        case GLP_GATE_U32_RANGE_CHECK: {
+            u32 k = 0; const u32 nin = g.p0;
+            for (u32 i = 0; i < nin; i++) {
+                const u64 *aux = W + (size_t)(nin + 16 * i) * N;
+                u64 sum = 0;
+                for (int j = 15; j >= 0; j--) sum = add(dbl(dbl(sum)), aux[(size_t)j * N]);
+                EMIT(k, sub(sum, W[(size_t)i * N])); k++;
+                for (int j = 0; j < 16; j++) { EMIT(k, range_product(aux[(size_t)j * N], 4)); k++; }
+            }
+            break;
+        }
+        case GLP_GATE_COMPARISON: {
+            u32 k = 0; const u32 nb = g.p0, ncx = g.p1, cb = (nb + ncx - 1) / ncx, cs = 1u << cb;
+            const u64 *ca = W + (size_t)4 * N, *cbp = ca + (size_t)ncx * N, *ed = cbp + (size_t)ncx * N;
+            const u64 *ceq = ed + (size_t)ncx * N, *iv = ceq + (size_t)ncx * N, *mb = iv + (size_t)ncx * N;
+            u64 fa = 0, fb = 0;
+            for (int i = (int)ncx - 1; i >= 0; i--) { fa = add(mul(fa, cs), ca[(size_t)i * N]); fb = add(mul(fb, cs), cbp[(size_t)i * N]); }
+            EMIT(k, sub(fa, W[0])); k++;
+            EMIT(k, sub(fb, W[N])); k++;
+            u64 msd = 0;
+            for (u32 i = 0; i < ncx; i++) {
+                const u64 ai = ca[(size_t)i * N], bi = cbp[(size_t)i * N], e = ceq[(size_t)i * N], inter = iv[(size_t)i * N];
+                EMIT(k, range_product(ai, cs)); k++;
+                EMIT(k, range_product(bi, cs)); k++;
+                const u64 diff = sub(bi, ai);
+                EMIT(k, sub(mul(diff, ed[(size_t)i * N]), sub(1, e))); k++;
+                EMIT(k, mul(e, diff)); k++;
+                EMIT(k, sub(inter, mul(e, msd))); k++;
+                msd = add(inter, mul(sub(1, e), diff));
+            }
+            const u64 msdw = W[(size_t)3 * N];
+            EMIT(k, sub(msdw, msd)); k++;
+            u64 bc = 0;
+            for (u32 j = 0; j <= cb; j++) { const u64 bit = mb[(size_t)j * N]; EMIT(k, mul(bit, sub(1, bit))); k++; }
+            for (int j = (int)cb; j >= 0; j--) bc = add(dbl(bc), mb[(size_t)j * N]);
+            EMIT(k, sub(add((u64)cs, msdw), bc)); k++;
+            EMIT(k, sub(W[(size_t)2 * N], mb[(size_t)cb * N])); k++;
+            break;
+        }
+        case GLP_GATE_BASE_SUM: {
+            u32 k = 0; const u32 nl = g.p0, Bb = g.p1;
+            u64 sum = 0;
+            for (int j = (int)nl - 1; j >= 0; j--) sum = add(mul(sum, Bb), W[(size_t)(1 + j) * N]);
+            EMIT(k, sub(sum, W[0])); k++;
+            for (u32 j = 0; j < nl; j++) { EMIT(k, range_product(W[(size_t)(1 + j) * N], Bb)); k++; }
+            break;
+        }
+        case GLP_GATE_RANDOM_ACCESS: {
+            u32 k = 0; const u32 bits = g.p0, copies = g.p1 & 0xFFFF, nextra = g.p1 >> 16, vs = 1u << bits;
+            const u32 routed = (2 + vs) * copies + nextra;
+            for (u32 cpy = 0; cpy < copies; cpy++) {
+                const u64 *bse = W + (size_t)((2 + vs) * cpy) * N, *bw = W + (size_t)(routed + bits * cpy) * N;
+                u64 list[32];
+                for (u32 j = 0; j < vs; j++) list[j] = bse[(size_t)(2 + j) * N];
+                u64 idx = 0;
+                for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; EMIT(k, mul(bit, sub(bit, 1))); k++; }
+                for (int b = (int)bits - 1; b >= 0; b--) idx = add(dbl(idx), bw[(size_t)b * N]);
+                EMIT(k, sub(idx, bse[0])); k++;
+                u32 len = vs;
+                for (u32 b = 0; b < bits; b++) {
+                    const u64 bit = bw[(size_t)b * N];
+                    for (u32 j = 0; j < len / 2; j++) list[j] = add(list[2 * j], mul(bit, sub(list[2 * j + 1], list[2 * j])));
+                    len >>= 1;
+                }
+                EMIT(k, sub(list[0], bse[N])); k++;
+            }
+            for (u32 e = 0; e < nextra; e++) { EMIT(k, sub(GC[(size_t)e * N], W[(size_t)((2 + vs) * copies + e) * N])); k++; }
             break;
         }
         default: break;   // NOOP
@@ -969,6 +1097,11 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         case GLP_GATE_NOOP: case GLP_GATE_CONSTANT: case GLP_GATE_PUBLIC_INPUT: case GLP_GATE_ARITHMETIC:
         case GLP_GATE_POSEIDON: if (g.type == GLP_GATE_POSEIDON && d.num_wires < 135) return set_error(GLP_ERR_ARG, "PoseidonGate needs 135 wires"); break;
         case GLP_GATE_U32_INTERLEAVE: case GLP_GATE_UNINTERLEAVE_U32: case GLP_GATE_UNINTERLEAVE_B32: break;
+        case GLP_GATE_U32_ARITHMETIC: case GLP_GATE_U32_ADD_MANY: case GLP_GATE_U32_SUBTRACTION:
+        case GLP_GATE_U32_RANGE_CHECK: case GLP_GATE_COMPARISON: case GLP_GATE_BASE_SUM: break;
+        case GLP_GATE_RANDOM_ACCESS:
+            GLP_REQUIRE(g.p0 >= 1 && g.p0 <= 5, "RandomAccessGate bits outside 1..5");
+            break;
         default: return set_error(GLP_ERR_UNSUPPORTED, "gate type %u is not built into the quotient kernel yet", g.type);
         }
         GLP_REQUIRE(g.selector_index < d.num_selectors && g.group_start <= g.row && g.row < g.group_end, "bad selector data for gate %u", i);

@@ -19,6 +19,8 @@ P = gl.P
 
 GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_POSEIDON = 0, 1, 2, 3, 4
 GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_U32, GATE_UNINTERLEAVE_B32 = 5, 6, 7
+GATE_U32_ARITHMETIC, GATE_U32_ADD_MANY, GATE_U32_SUBTRACTION, GATE_U32_RANGE_CHECK = 8, 9, 10, 11
+GATE_COMPARISON, GATE_BASE_SUM, GATE_RANDOM_ACCESS = 12, 13, 14
 
 # (degree, id string as plonky2's `Gate::id` prints it) -- the build() sort key
 _GATE_META = {
@@ -30,12 +32,29 @@ _GATE_META = {
     GATE_U32_INTERLEAVE: (2, "U32InterleaveGate {{ num_ops: {p0} }}"),
     GATE_UNINTERLEAVE_U32: (2, "UninterleaveToU32Gate {{ num_ops: {p0} }}"),
     GATE_UNINTERLEAVE_B32: (2, "UninterleaveToB32Gate {{ num_ops: {p0} }}"),
+    GATE_U32_ARITHMETIC: (4, "U32ArithmeticGate {{ num_ops: {p0} }}"),
+    GATE_U32_ADD_MANY: (4, "U32AddManyGate {{ num_addends: {p0}, num_ops: {p1} }}"),
+    GATE_U32_SUBTRACTION: (4, "U32SubtractionGate {{ num_ops: {p0} }}"),
+    GATE_U32_RANGE_CHECK: (4, "U32RangeCheckGate {{ num_input_limbs: {p0} }}"),
+    GATE_COMPARISON: (4, "ComparisonGate {{ num_bits: {p0}, num_chunks: {p1} }}"),
+    GATE_BASE_SUM: (4, "BaseSumGate {{ num_limbs: {p0} }} + Base: {p1}"),
+    GATE_RANDOM_ACCESS: (5, "RandomAccessGate {{ bits: {p0} }}"),
 }
 
 
-def gate_num_constraints(t, p0):
+def gate_num_constraints(t, p0, p1=0):
+    if t == GATE_U32_ADD_MANY:
+        return p1 * 21
+    if t == GATE_COMPARISON:
+        cb = -(-p0 // p1)
+        return 2 + 5 * p1 + 1 + (cb + 1) + 2
+    if t == GATE_BASE_SUM:
+        return 1 + p0
+    if t == GATE_RANDOM_ACCESS:
+        return (p1 & 0xFFFF) * (p0 + 2) + (p1 >> 16)
     return {GATE_NOOP: 0, GATE_CONSTANT: p0, GATE_PUBLIC_INPUT: 4, GATE_ARITHMETIC: p0, GATE_POSEIDON: 123,
-            GATE_U32_INTERLEAVE: p0 * 34, GATE_UNINTERLEAVE_U32: p0 * 67, GATE_UNINTERLEAVE_B32: p0 * 67}[t]
+            GATE_U32_INTERLEAVE: p0 * 34, GATE_UNINTERLEAVE_U32: p0 * 67, GATE_UNINTERLEAVE_B32: p0 * 67,
+            GATE_U32_ARITHMETIC: p0 * 36, GATE_U32_SUBTRACTION: p0 * 19, GATE_U32_RANGE_CHECK: p0 * 17}[t]
 
 
 class Config:
@@ -103,11 +122,11 @@ class Builder:
         self.public_inputs = np.zeros(0, dtype=np.uint64)
         self._kind(GATE_NOOP, 0)
 
-    def _kind(self, t, p0):
-        return self.gate_kinds.setdefault((t, p0), len(self.gate_kinds))
+    def _kind(self, t, p0, p1=0):
+        return self.gate_kinds.setdefault((t, p0, p1), len(self.gate_kinds))
 
-    def set_rows(self, rows, t, p0):
-        self.row_gate[rows] = self._kind(t, p0)
+    def set_rows(self, rows, t, p0, p1=0):
+        self.row_gate[rows] = self._kind(t, p0, p1)
 
     def connect_pairs(self, rows_a, col_a, rows_b, col_b):
         """2-cycles between fresh cells (rows_a[i], col_a) <-> (rows_b[i], col_b)."""
@@ -123,8 +142,9 @@ class Builder:
     def build(self):
         cfg, n, lg = self.cfg, self.n, self.log_n
         c = Circuit()
-        kinds = sorted(self.gate_kinds.items(), key=lambda kv: (_GATE_META[kv[0][0]][0], _GATE_META[kv[0][0]][1].format(p0=kv[0][1])))
-        gates = [(_GATE_META[t][0], t, p0) for (t, p0), _ in kinds]
+        kinds = sorted(self.gate_kinds.items(),
+                       key=lambda kv: (_GATE_META[kv[0][0]][0], _GATE_META[kv[0][0]][1].format(p0=kv[0][1], p1=kv[0][2])))
+        gates = [(_GATE_META[t][0], t, p0, p1) for (t, p0, p1), _ in kinds]
         key_to_index = {key: i for i, (_, key) in enumerate(kinds)}
         sel_idx, groups = _selector_groups(gates, cfg.max_quotient_degree_factor + 1)
         num_selectors = len(groups)
@@ -136,9 +156,9 @@ class Builder:
             consts[g] = np.where(in_group, gate_index.astype(np.uint64), np.uint64(0xFFFFFFFF)) if num_selectors > 1 \
                 else gate_index.astype(np.uint64)
         consts[num_selectors:] = self.gate_consts
-        c.gates = [dict(type=t, p0=p0, p1=0, selector_index=sel_idx[i], group_start=groups[sel_idx[i]][0],
-                        group_end=groups[sel_idx[i]][1], row=i, num_constraints=gate_num_constraints(t, p0))
-                   for i, (_, t, p0) in enumerate(gates)]
+        c.gates = [dict(type=t, p0=p0, p1=p1, selector_index=sel_idx[i], group_start=groups[sel_idx[i]][0],
+                        group_end=groups[sel_idx[i]][1], row=i, num_constraints=gate_num_constraints(t, p0, p1))
+                   for i, (_, t, p0, p1) in enumerate(gates)]
         c.degree_bits = lg
         c.num_wires, c.num_routed_wires = cfg.num_wires, cfg.num_routed_wires
         c.num_constants, c.num_selectors = consts.shape[0], num_selectors
@@ -158,7 +178,123 @@ class Builder:
         return c
 
 
-def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, num_const_rows=4, num_noop_rows=3):
+def _digits(v, base_bits, count):
+    return [(v >> (base_bits * j)) & ((1 << base_bits) - 1) for j in range(count)]
+
+
+def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
+    """Rows of the seven remaining gate types of the secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96]
+    with the parameters `standard_ecc_config` gives them (136 wires / 80 routed / 2 constants), each with a
+    satisfying witness built from the gate's definition.  Returns the next free row."""
+    cfg, w, rng = b.cfg, b.wires, b.rng
+    nw, nr = cfg.num_wires, cfg.num_routed_wires
+    M32 = (1 << 32) - 1
+    ri = lambda hi: int(rng.integers(0, hi))
+    row = first_row
+    # U32ArithmeticGate: m0*m1 + addend = out_hi 2^32 + out_lo
+    n_ops = min(nr // 6, nw // 38)
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_U32_ARITHMETIC, n_ops)
+        for i in range(n_ops):
+            m0, m1, ad = ri(1 << 32), ri(1 << 32), ri(1 << 32)
+            prod = m0 * m1 + ad
+            lo, hi = prod & M32, prod >> 32
+            w[6 * i:6 * i + 6, row] = [m0, m1, ad, lo, hi, pow((M32 - hi) % P, P - 2, P)]
+            w[6 * n_ops + 32 * i:6 * n_ops + 32 * i + 32, row] = _digits(prod, 2, 32)
+        row += 1
+    # U32AddManyGate, 3 addends
+    na = 3
+    n_ops = min(nr // (na + 3), nw // (na + 3 + 18))
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_U32_ADD_MANY, na, n_ops)
+        for i in range(n_ops):
+            vals = [ri(1 << 32) for _ in range(na + 1)]
+            tot = sum(vals)
+            o = (na + 3) * i
+            w[o:o + na + 1, row] = vals
+            w[o + na + 1, row], w[o + na + 2, row] = tot & M32, tot >> 32
+            lo = (na + 3) * n_ops + 18 * i
+            w[lo:lo + 16, row] = _digits(tot & M32, 2, 16)
+            w[lo + 16:lo + 18, row] = _digits(tot >> 32, 2, 2)
+        row += 1
+    # U32SubtractionGate
+    n_ops = min(nr // 5, nw // 21)
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_U32_SUBTRACTION, n_ops)
+        for i in range(n_ops):
+            x, y, bi = ri(1 << 32), ri(1 << 32), ri(2)
+            d = x - y - bi
+            bo = 1 if d < 0 else 0
+            res = d + (bo << 32)
+            w[5 * i:5 * i + 5, row] = [x, y, bi, res, bo]
+            w[5 * n_ops + 16 * i:5 * n_ops + 16 * i + 16, row] = _digits(res, 2, 16)
+        row += 1
+    # U32RangeCheckGate, 8 limbs (exactly 136 wires)
+    n_in = 8
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_U32_RANGE_CHECK, n_in)
+        for i in range(n_in):
+            v = ri(1 << 32)
+            w[i, row] = v
+            w[n_in + 16 * i:n_in + 16 * i + 16, row] = _digits(v, 2, 16)
+        row += 1
+    # ComparisonGate(32 bits, 16 chunks)
+    nbits, nch = 32, 16
+    cb = nbits // nch
+    for k in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_COMPARISON, nbits, nch)
+        first, second = ri(1 << 32), ri(1 << 32)
+        if k == 1:
+            second = first                      # all chunks equal
+        a, bb = _digits(first, cb, nch), _digits(second, cb, nch)
+        ed, ce, iv, msd = [], [], [], 0
+        for i in range(nch):
+            diff = (bb[i] - a[i]) % P
+            eq = 1 if diff == 0 else 0
+            ed.append(1 if eq else pow(diff, P - 2, P))
+            ce.append(eq)
+            inter = eq * msd % P
+            iv.append(inter)
+            msd = (inter + (1 - eq) * diff) % P
+        top = ((1 << cb) + msd) % P
+        bits = _digits(top, 1, cb + 1)
+        w[0, row], w[1, row], w[2, row], w[3, row] = first, second, bits[cb], msd
+        o = 4
+        for arr in (a, bb, ed, ce, iv, bits):
+            w[o:o + len(arr), row] = arr
+            o += len(arr)
+        assert bits[cb] == (1 if first <= second else 0)
+        row += 1
+    # BaseSumGate<4>, 16 limbs
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_BASE_SUM, 16, 4)
+        v = ri(1 << 32)
+        w[0, row] = v
+        w[1:17, row] = _digits(v, 2, 16)
+        row += 1
+    # RandomAccessGate(bits = 4)
+    bits_ra = 4
+    vs = 1 << bits_ra
+    copies = min(nr // (2 + vs), nw // (2 + vs + bits_ra))
+    nextra = min(nr - copies * (2 + vs), cfg.num_constants)
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_RANDOM_ACCESS, bits_ra, copies | (nextra << 16))
+        for c in range(copies):
+            idx = ri(vs)
+            lst = [int(x) for x in gl.rand(rng, vs)]
+            o = (2 + vs) * c
+            w[o, row], w[o + 1, row] = idx, lst[idx]
+            w[o + 2:o + 2 + vs, row] = lst
+            w[(2 + vs) * copies + nextra + bits_ra * c:(2 + vs) * copies + nextra + bits_ra * (c + 1), row] = _digits(idx, 1, bits_ra)
+        ex = [int(x) for x in gl.rand(rng, nextra)]
+        b.gate_consts[:nextra, row] = ex
+        w[(2 + vs) * copies:(2 + vs) * copies + nextra, row] = ex
+        row += 1
+    return row
+
+
+def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, num_const_rows=4, num_noop_rows=3,
+                  ecdsa_gate_rows=0):
     """ECDSA-shaped stand-in: one PublicInputGate row, a few ConstantGate rows, ArithmeticGate rows
     (20 ops wide for 80 routed wires) chained through copy constraints, NoopGate padding."""
     cfg = config or Config.standard_ecc_config()
@@ -172,11 +308,14 @@ def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, nu
             raise ValueError("pass pi_hash = hash_no_pad(public_inputs) when public inputs are non-empty")
         pi_hash = np.zeros(4, np.uint64)
     need_const_rows = max(num_const_rows, 2)
-    if n < 1 + need_const_rows + num_noop_rows + 2:
+    if n < 1 + need_const_rows + num_noop_rows + 2 + 7 * ecdsa_gate_rows:
         raise ValueError("log_n too small")
     row_pi = 0
     rows_c = np.arange(1, 1 + need_const_rows)
-    rows_a = np.arange(1 + need_const_rows, n - num_noop_rows)
+    first_arith = 1 + need_const_rows
+    if ecdsa_gate_rows:
+        first_arith = fill_ecdsa_gate_rows(b, first_arith, ecdsa_gate_rows)
+    rows_a = np.arange(first_arith, n - num_noop_rows)
     b.set_rows(np.array([row_pi]), GATE_PUBLIC_INPUT, 0)
     b.set_rows(rows_c, GATE_CONSTANT, cfg.num_constants)
     b.set_rows(rows_a, GATE_ARITHMETIC, num_ops)
@@ -209,6 +348,13 @@ def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, nu
             b.wires[4 * (j + 1) + 2, rows_a] = out
             b.connect_pairs(rows_a, 4 * j + 3, rows_a, 4 * (j + 1) + 2)
     return b.build()
+
+
+def ecdsa_shape_circuit(log_n, seed=3, rows_per_gate=2):
+    """The headline stand-in: `standard_ecc_config`, every one of the 11 gate types the reference registers for
+    its secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96] present (so the quotient kernel evaluates the
+    same constraint set at every point, in three selector groups), ArithmeticGate rows filling the trace."""
+    return arith_circuit(log_n, Config.standard_ecc_config(), seed=seed, ecdsa_gate_rows=rows_per_gate)
 
 
 def u32_circuit(log_n=6, config=None, seed=2):

@@ -71,6 +71,15 @@ def test_prove_parity_reference_u32_gates(ctx, oracle):
     _check(ctx, oracle, desc)
 
 
+def test_prove_parity_ecdsa_gate_set(ctx, oracle):
+    """BASELINE config 3 gate set: all 11 gate types of the secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96]
+    in three selector groups, standard_ecc_config."""
+    desc = synth.ecdsa_shape_circuit(7)
+    assert desc.num_selectors == 3 and desc.num_gate_constraints == 136 and len(desc.gates) == 11
+    _check(ctx, oracle, desc)
+    _check(ctx, oracle, synth.ecdsa_shape_circuit(10, seed=8, rows_per_gate=5))
+
+
 def test_prove_parity_zkdsa_circuit(ctx, oracle):
     """BASELINE config 5: the simple-signature circuit, 2^3 rows, 4 PoseidonGate rows, 12 public inputs, two
     selector groups (PoseidonGate has degree 7)."""

@@ -119,28 +119,29 @@ struct PPArgs {
     u32 lg, nr, nch, npp, qdf;
 };
 // K5a: per row, the running products of the quotient chunks  prod_{j in chunk} (w_j + beta k_j x + gamma)/(w_j + beta sigma_j + gamma)
+template <int NCH>
 __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
     const size_t n = (size_t)1 << a.lg;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const u64 x = dpow(a.w_n, i);
     u64 cum[MAXCH];
-    for (u32 c = 0; c < a.nch; c++) cum[c] = 1;
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) cum[c] = 1;
     for (u32 chunk = 0; chunk <= a.npp; chunk++) {
         u64 num[MAXCH], den[MAXCH];
-        for (u32 c = 0; c < a.nch; c++) { num[c] = 1; den[c] = 1; }
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
         const u32 j1 = min((chunk + 1) * a.qdf, a.nr);
         for (u32 j = chunk * a.qdf; j < j1; j++) {
             const u64 w = a.wires[(size_t)j * n + i], s = a.sigmas[(size_t)j * n + i];
             const u64 kx = mul(a.k_is[j], x);
-            for (u32 c = 0; c < a.nch; c++) {
+            _Pragma("unroll") for (int c = 0; c < NCH; c++) {
                 num[c] = mul(num[c], add(add(w, mul(a.betas[c], kx)), a.gammas[c]));
                 den[c] = mul(den[c], add(add(w, mul(a.betas[c], s)), a.gammas[c]));
             }
         }
-        for (u32 c = 0; c < a.nch; c++) {
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) {
             cum[c] = mul(cum[c], mul(num[c], inv(den[c])));
-            const u32 col = chunk < a.npp ? a.nch + c * a.npp + chunk : c;   // Z column holds the row product for now
+            const u32 col = chunk < a.npp ? NCH + c * a.npp + chunk : c;   // Z column holds the row product for now
             a.zp[(size_t)col * n + i] = cum[c];
         }
     }
@@ -199,9 +200,34 @@ __global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 l
 }
 
 __device__ __forceinline__ u64 range_product(u64 v, u32 bound) {   // prod_{x < bound} (v - x)
+    if (bound == 4) {                       // v(v-3) * (v-1)(v-2) = u (u + 2): two multiplications instead of three
+        const u64 u = mul(v, sub(v, 3));
+        return mul(u, add(u, 2));
+    }
     u64 p = v;
     for (u32 x = 1; x < bound; x++) p = mul(p, sub(v, (u64)x));
     return p;
+}
+// Unreduced accumulator for sum_k c_k * alpha^k: 128-bit products are added into five 32-bit words and folded
+// once per gate instead of once per constraint (a modular multiply-add costs ~40 issue slots, this ~19).
+struct Acc160 { u32 w0, w1, w2, w3, w4; };
+__device__ __forceinline__ void acc_zero(Acc160 &a) { a.w0 = a.w1 = a.w2 = a.w3 = a.w4 = 0; }
+__device__ __forceinline__ void acc_fma(Acc160 &a, u64 v, u64 m) {
+    const u32 v0 = (u32)v, v1 = (u32)(v >> 32), m0 = (u32)m, m1 = (u32)(m >> 32);
+    const u64 p00 = (u64)v0 * m0;
+    const u64 p01 = (u64)v0 * m1 + (p00 >> 32);
+    const u64 p10 = (u64)v1 * m0 + (u32)p01;
+    const u64 p11 = (u64)v1 * m1 + (p01 >> 32) + (p10 >> 32);
+    u32 c;
+    a.w0 = __builtin_addc(a.w0, (u32)p00, 0u, &c);
+    a.w1 = __builtin_addc(a.w1, (u32)p10, c, &c);
+    a.w2 = __builtin_addc(a.w2, (u32)p11, c, &c);
+    a.w3 = __builtin_addc(a.w3, (u32)(p11 >> 32), c, &c);
+    a.w4 += c;
+}
+__device__ __forceinline__ u64 acc_reduce(const Acc160 &a) {      // canonical
+    const u64 h = fold96_nc(((u64)a.w3 << 32) | a.w2, a.w4);       // (w2 + w3 2^32 + w4 2^64) mod p
+    return canon(fold128_nc(a.w0, a.w1, (u32)h, (u32)(h >> 32)));
 }
 
 struct QArgs {
@@ -216,41 +242,44 @@ struct QArgs {
 };
 // K6: vanishing polynomial / Z_H on the planes r = 0, step, 2 step, ... of the coset-major LDE domain.
 //   terms: [L_0 (Z_c - 1)]_c, [prev*num - next*den]_{c,chunk}, gate constraints; res_c = sum_k term_k alpha_c^k
-__global__ __launch_bounds__(256) void k_quotient(QArgs a) {
+template <int NCH>
+__global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     const u32 rq = blockIdx.y, r = rq * a.step;
     const size_t slot = (size_t)r * n + q, slot_next = (size_t)r * n + ((q + 1) & (n - 1));
     const u64 x = mul(a.shift_r[rq], dpow(a.w_n, q));
-    const u32 nch = a.nch, nchunks = a.npp + 1, nt = a.nterms;
+    constexpr u32 nch = NCH; const u32 nchunks = a.npp + 1, nt = a.nterms;
     u64 acc[MAXCH], zx[MAXCH], zg[MAXCH];
-    for (u32 c = 0; c < nch; c++) { acc[c] = 0; zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
+    Acc160 pa[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) { acc_zero(pa[c]); zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
     const u64 l0 = mul(a.zh[rq], inv(mul(a.n_field, sub(x, 1))));
-    for (u32 c = 0; c < nch; c++) {
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
         const u64 t = mul(l0, sub(zx[c], 1));
-        for (u32 c2 = 0; c2 < nch; c2++) acc[c2] = add(acc[c2], mul(t, a.apow[c2 * nt + c]));
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + c]);
     }
     for (u32 chunk = 0; chunk < nchunks; chunk++) {
         u64 num[MAXCH], den[MAXCH];
-        for (u32 c = 0; c < nch; c++) { num[c] = 1; den[c] = 1; }
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
         const u32 j1 = min((chunk + 1) * a.qdf, a.nr);
         for (u32 j = chunk * a.qdf; j < j1; j++) {
             const u64 w = a.wl[(size_t)j * N + slot], s = a.cs[(size_t)(a.nc + j) * N + slot];
             const u64 kx = mul(a.k_is[j], x);
-            for (u32 c = 0; c < nch; c++) {
+            _Pragma("unroll") for (int c = 0; c < NCH; c++) {
                 num[c] = mul(num[c], add(add(w, mul(a.betas[c], kx)), a.gammas[c]));
                 den[c] = mul(den[c], add(add(w, mul(a.betas[c], s)), a.gammas[c]));
             }
         }
-        for (u32 c = 0; c < nch; c++) {
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) {
             const u64 prev = chunk == 0 ? zx[c] : a.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
             const u64 next = chunk == nchunks - 1 ? zg[c] : a.zl[(size_t)(nch + c * a.npp + chunk) * N + slot];
             const u64 t = sub(mul(prev, num[c]), mul(next, den[c]));
             const u32 k = nch + c * nchunks + chunk;
-            for (u32 c2 = 0; c2 < nch; c2++) acc[c2] = add(acc[c2], mul(t, a.apow[c2 * nt + k]));
+            _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + k]);
         }
     }
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
     const u32 k0 = nch + nch * nchunks;
     const u64 *W = a.wl + slot;                       // wire j  -> W[j * N]
     const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
@@ -261,13 +290,13 @@ __global__ __launch_bounds__(256) void k_quotient(QArgs a) {
         for (u32 i = g.group_start; i < g.group_end; i++)
             if (i != g.row) filter = mul(filter, sub((u64)i, s));
         if (a.many_selectors) filter = mul(filter, sub(0xFFFFFFFFull, s));
-        u64 ga[MAXCH];
-        for (u32 c = 0; c < nch; c++) ga[c] = 0;
+        Acc160 ga[MAXCH];
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc_zero(ga[c]);
         const u64 *ap = a.apow + k0;
 #define EMIT(k, v)                                                                     \
     do {                                                                               \
         const u64 _v = (v);                                                            \
-        for (u32 c2 = 0; c2 < nch; c2++) ga[c2] = add(ga[c2], mul(_v, ap[c2 * nt + (k)])); \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(ga[c2], _v, ap[c2 * nt + (k)]);       \
     } while (0)
         switch (g.type) {
         case GLP_GATE_CONSTANT:
@@ -473,19 +502,32 @@ __global__ __launch_bounds__(256) void k_quotient(QArgs a) {
             const u32 routed = (2 + vs) * copies + nextra;
             for (u32 cpy = 0; cpy < copies; cpy++) {
                 const u64 *bse = W + (size_t)((2 + vs) * cpy) * N, *bw = W + (size_t)(routed + bits * cpy) * N;
-                u64 list[32];
-                for (u32 j = 0; j < vs; j++) list[j] = bse[(size_t)(2 + j) * N];
                 u64 idx = 0;
                 for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; EMIT(k, mul(bit, sub(bit, 1))); k++; }
                 for (int b = (int)bits - 1; b >= 0; b--) idx = add(dbl(idx), bw[(size_t)b * N]);
                 EMIT(k, sub(idx, bse[0])); k++;
-                u32 len = vs;
-                for (u32 b = 0; b < bits; b++) {
-                    const u64 bit = bw[(size_t)b * N];
-                    for (u32 j = 0; j < len / 2; j++) list[j] = add(list[2 * j], mul(bit, sub(list[2 * j + 1], list[2 * j])));
-                    len >>= 1;
+                u64 sel;
+                if (bits == 4) {           // the width the reference uses; folded in registers
+                    const u64 b0 = bw[0], b1 = bw[N], b2 = bw[2 * N], b3 = bw[3 * N];
+                    u64 l2[4];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        const u64 *it = bse + (size_t)(2 + 4 * q4) * N;
+                        const u64 i0 = it[0], i1 = it[N], i2 = it[2 * N], i3 = it[3 * N];
+                        const u64 f0 = add(i0, mul(b0, sub(i1, i0))), f1 = add(i2, mul(b0, sub(i3, i2)));
+                        l2[q4] = add(f0, mul(b1, sub(f1, f0)));
+                    }
+                    const u64 g0 = add(l2[0], mul(b2, sub(l2[1], l2[0]))), g1 = add(l2[2], mul(b2, sub(l2[3], l2[2])));
+                    sel = add(g0, mul(b3, sub(g1, g0)));
+                } else {                   // generic width: select by recursion over the index bits (no local array)
+                    sel = 0;
+                    for (u32 j = 0; j < vs; j++) {
+                        u64 ind = 1;       // product over bits of (bit or 1 - bit): Lagrange indicator of slot j
+                        for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; ind = mul(ind, ((j >> b) & 1) ? bit : sub(1, bit)); }
+                        sel = add(sel, mul(ind, bse[(size_t)(2 + j) * N]));
+                    }
                 }
-                EMIT(k, sub(list[0], bse[N])); k++;
+                EMIT(k, sub(sel, bse[N])); k++;
             }
             for (u32 e = 0; e < nextra; e++) { EMIT(k, sub(GC[(size_t)e * N], W[(size_t)((2 + vs) * copies + e) * N])); k++; }
             break;
@@ -493,10 +535,10 @@ __global__ __launch_bounds__(256) void k_quotient(QArgs a) {
         default: break;   // NOOP
         }
 #undef EMIT
-        for (u32 c = 0; c < nch; c++) acc[c] = add(acc[c], mul(filter, ga[c]));
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc_reduce(ga[c])));
     }
     const size_t Rq = (size_t)gridDim.y;
-    for (u32 c = 0; c < nch; c++) a.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) a.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
 }
 
 // K6b: after the per-plane inverse NTT: undo the plane twist, inverse DFT across planes, undo the coset shift.
@@ -762,7 +804,12 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
             a.wires = dev_wires; a.sigmas = cc->dev_sigmas; a.k_is = cc->dev_k_is; a.zp = zp;
             for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
             a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
-            hipLaunchKernelGGL(k_pp_rows, dim3(nblocks), dim3(256), 0, c->stream, a);
+            switch (nch) {
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<1>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<2>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
+            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<3>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<4>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
+            }
             GLP_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_pp_block_tot, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks);
             hipLaunchKernelGGL(k_pp_scan_tot, dim3(nch), dim3(256), 0, c->stream, tot, nblocks);
@@ -809,7 +856,12 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
         a.many_selectors = d.num_selectors > 1;
         {
             StageScope st(c, "quotient_eval", 8.0 * n * Rq * (nc + nr + nw + nzp + 2.0 * nch));
-            hipLaunchKernelGGL(k_quotient, dim3(nblk(n), Rq), dim3(256), 0, c->stream, a);
+            switch (nch) {
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            }
             GLP_HIP(hipGetLastError());
         }
         {

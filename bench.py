@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--log-n", type=int, default=20, help="trace rows = 2^log_n (headline: 20)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=12, help="rows of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default=None, help="override the torch.distributed backend (rehearsals: gloo)")
+    ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     return ap.parse_args()
 
 
@@ -99,8 +101,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libglprover has no CPU path")
-    grp = gdist.init_from_env(use_cuda=True)
-    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    grp = gdist.init_from_env(use_cuda=True, backend=a.dist_backend, force_device=a.force_device)
+    rank, world = grp.rank, grp.world
+    local_rank = grp.local_rank if a.force_device is None else a.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

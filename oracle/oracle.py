@@ -262,7 +262,8 @@ class _Circuit(C.Structure):
 class OracleCircuit:
     """Wraps a plonky2_lib_amd.synth.Circuit (plain attribute bag) for the C oracle."""
 
-    def __init__(self, c):
+    def __init__(self, c, cs_cap=None):
+        """cs_cap: optional constants+sigmas Merkle cap (verifier_only data); if omitted it is computed here."""
         self.c = c
         self._k = _a(c.k_is); self._const = _a(c.constants); self._sig = _a(c.sigmas)
         self._gates = (_Gate * len(c.gates))()
@@ -284,8 +285,11 @@ class OracleCircuit:
         self.s = s
         L = lib()
         L.glo_proof_words.restype = C.c_size_t
-        self.cs_cap = np.empty((1 << c.cap_height, 4), np.uint64)
-        L.glo_constants_sigmas_cap(C.byref(s), _p(self.cs_cap))
+        if cs_cap is None:
+            self.cs_cap = np.empty((1 << c.cap_height, 4), np.uint64)
+            L.glo_constants_sigmas_cap(C.byref(s), _p(self.cs_cap))
+        else:
+            self.cs_cap = _a(cs_cap).reshape(1 << c.cap_height, 4).copy()
         if getattr(c, "circuit_digest", None) is None:
             c.circuit_digest = circuit_digest(self.cs_cap, c.degree_bits)
         for i in range(4):

@@ -14,7 +14,8 @@
 
 namespace glp {
 
-constexpr int NTT_MAX_LG = 20;      // two-pass limit: B <= 2^12 (contiguous), A <= 2^8 (strided)
+constexpr int NTT_2PASS_LG = 20;    // two-pass limit: B <= 2^12 (contiguous), A <= 2^8 (strided)
+constexpr int NTT_MAX_LG = 24;      // above 2^20: an outer strided pass over A' = n / 2^20 <= 16 blocks (three passes)
 constexpr int NTT_LGB_MAX = 12;
 constexpr int NTT_LGA_MAX = 8;
 constexpr int NTT_STRIDED_W = 16;   // columns per strided tile (16 x 8 B = one 128-B line per row)
@@ -25,6 +26,11 @@ struct NttPlan {
     u64 *tw_A = nullptr, *itw_A = nullptr;   // w_A^j / w_A^-j, j < A/2
     u64 *tw4096 = nullptr, *itw4096 = nullptr;  // w_4096^(+-j), j < 4096: inter-step twiddles of the radix-16 kernels
     u64 w_n, w_n_inv, n_inv;
+    // lg > NTT_2PASS_LG only: n = A' * 2^20
+    int lgAo = 0;
+    const NttPlan *inner = nullptr;          // the 2^20 plan
+    u64 *tw_Ao = nullptr, *itw_Ao = nullptr; // w_A'^(+-j), j < A'/2
+    u64 *it0 = nullptr, *it1 = nullptr;      // inverse outer twiddle: (w_n^-k1o)^q = it1[pbo][q >> 10] * it0[pbo][q & 1023], it1 carries 1/A'
 };
 
 struct LdePlan {
@@ -33,6 +39,9 @@ struct LdePlan {
     u64 shift;
     u64 *pre = nullptr;      // [R][B]: (s_r^A)^bitrev_B(pl),  s_r = shift * W^r
     u64 *s_r = nullptr;      // [R]
+    // lg > NTT_2PASS_LG only
+    const LdePlan *inner = nullptr;          // (2^20, rate_bits, shift^A')
+    u64 *t0 = nullptr, *t1 = nullptr;        // outer twiddle s_r^k1o (w_n^k1o)^q = t1[r][pbo][q >> 10] * t0[pbo][q & 1023]
 };
 
 int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out);

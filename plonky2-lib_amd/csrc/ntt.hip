@@ -27,6 +27,31 @@ int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out) {
     if (it != c->ntt_plans.end()) { *out = it->second; return GLP_OK; }
     std::unique_ptr<NttPlan> p(new NttPlan());
     p->lg = lg;
+    if (lg > NTT_2PASS_LG) {
+        NttPlan *in;
+        GLP_TRY(get_ntt_plan(c, NTT_2PASS_LG, &in));
+        p->inner = in;
+        p->lgAo = lg - NTT_2PASS_LG;
+        p->lgB = in->lgB; p->lgA = in->lgA;
+        p->w_n = root_of_unity(lg); p->w_n_inv = inv(p->w_n); p->n_inv = inv((u64)1 << lg);
+        const size_t Ao = (size_t)1 << p->lgAo;
+        std::vector<u64> f(Ao / 2), b(Ao / 2), t0(Ao * 1024), t1(Ao * 1024);
+        const u64 wA = root_of_unity(p->lgAo), wAi = inv(wA), ainv = inv((u64)Ao);
+        u64 x = 1, y = 1;
+        for (size_t j = 0; j < Ao / 2; j++) { f[j] = x; b[j] = y; x = mul(x, wA); y = mul(y, wAi); }
+        for (size_t pbo = 0; pbo < Ao; pbo++) {
+            const u64 base = pow(p->w_n_inv, (u64)bitrev32((u32)pbo, p->lgAo)), base1024 = pow(base, 1024);
+            u64 a0 = 1, a1 = ainv;
+            for (size_t j = 0; j < 1024; j++) { t0[pbo * 1024 + j] = a0; t1[pbo * 1024 + j] = a1; a0 = mul(a0, base); a1 = mul(a1, base1024); }
+        }
+        GLP_TRY(upload(c, f, &p->tw_Ao));
+        GLP_TRY(upload(c, b, &p->itw_Ao));
+        GLP_TRY(upload(c, t0, &p->it0));
+        GLP_TRY(upload(c, t1, &p->it1));
+        *out = p.get();
+        c->ntt_plans[lg] = p.release();
+        return GLP_OK;
+    }
     p->lgB = lg < NTT_LGB_MAX ? lg : NTT_LGB_MAX;
     p->lgA = lg - p->lgB;
     p->w_n = root_of_unity(lg);
@@ -71,6 +96,29 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
     std::unique_ptr<LdePlan> p(new LdePlan());
     p->ntt = np; p->rate_bits = rate_bits; p->shift = shift;
     const int R = 1 << rate_bits;
+    if (lg > NTT_2PASS_LG) {
+        const size_t Ao = (size_t)1 << np->lgAo;
+        LdePlan *in;
+        GLP_TRY(get_lde_plan(c, NTT_2PASS_LG, rate_bits, pow(shift, (u64)Ao), &in));
+        p->inner = in;
+        const u64 Wbig = root_of_unity(lg + rate_bits);
+        std::vector<u64> t0(Ao * 1024), t1((size_t)R * Ao * 1024);
+        for (size_t pbo = 0; pbo < Ao; pbo++) {
+            const u64 k1o = bitrev32((u32)pbo, np->lgAo);
+            const u64 base = pow(np->w_n, k1o), base1024 = pow(base, 1024);
+            u64 a0 = 1;
+            for (size_t j = 0; j < 1024; j++) { t0[pbo * 1024 + j] = a0; a0 = mul(a0, base); }
+            for (int r = 0; r < R; r++) {
+                u64 a1 = pow(mul(shift, pow(Wbig, (u64)r)), k1o);      // s_r^k1o
+                for (size_t j = 0; j < 1024; j++) { t1[((size_t)r * Ao + pbo) * 1024 + j] = a1; a1 = mul(a1, base1024); }
+            }
+        }
+        GLP_TRY(upload(c, t0, &p->t0));
+        GLP_TRY(upload(c, t1, &p->t1));
+        *out = p.get();
+        c->lde_plans[key] = p.release();
+        return GLP_OK;
+    }
     const size_t B = (size_t)1 << np->lgB, A = (size_t)1 << np->lgA;
     const u64 Wbig = root_of_unity(lg + rate_bits);
     std::vector<u64> s(R), pre((size_t)R * B);
@@ -92,11 +140,15 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
 }
 
 void free_plans(glp_ctx *c) {
-    for (auto &kv : c->lde_plans) { (void)hipFree(kv.second->pre); (void)hipFree(kv.second->s_r); delete kv.second; }
+    for (auto &kv : c->lde_plans) {
+        (void)hipFree(kv.second->pre); (void)hipFree(kv.second->s_r); (void)hipFree(kv.second->t0); (void)hipFree(kv.second->t1);
+        delete kv.second;
+    }
     c->lde_plans.clear();
     for (auto &kv : c->ntt_plans) {
         (void)hipFree(kv.second->tw_B); (void)hipFree(kv.second->itw_B); (void)hipFree(kv.second->tw_A); (void)hipFree(kv.second->itw_A);
         (void)hipFree(kv.second->tw4096); (void)hipFree(kv.second->itw4096);
+        (void)hipFree(kv.second->tw_Ao); (void)hipFree(kv.second->itw_Ao); (void)hipFree(kv.second->it0); (void)hipFree(kv.second->it1);
         delete kv.second;
     }
     c->ntt_plans.clear();
@@ -310,6 +362,18 @@ __global__ __launch_bounds__(TPB) void k_intt_contig(const u64 *__restrict__ in,
     }
 }
 
+// Outer twiddle of the three-pass transform: data [planes][A'][M]; element (plane, pbo, q) *= t1[rsel][pbo][q >> 10] * t0[pbo][q & 1023]
+// with rsel = plane % R.  grid = (M / 256, planes * A')
+__global__ __launch_bounds__(256) void k_big_twiddle(u64 *__restrict__ data, const u64 *__restrict__ t0, const u64 *__restrict__ t1,
+                                                     int lgAo, int lgM, int R) {
+    const size_t M = (size_t)1 << lgM;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 blk = blockIdx.y, pbo = blk & ((1u << lgAo) - 1), plane = blk >> lgAo, r = plane % (u32)R;
+    const u64 f = mul_nc(t1[(((size_t)r << lgAo) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]);
+    u64 *p = data + (size_t)blk * M + q;
+    *p = mul_c(*p, f);
+}
+
 __global__ void k_bitrev_copy(const u64 *__restrict__ in, u64 *__restrict__ out, int lg) {
     const size_t n = (size_t)1 << lg;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -389,7 +453,7 @@ constexpr int R16_LDS = 17 * 256;       // 16 x 16 x 16 tile, rows of 16 padded 
 // tile slot 256 rc + 16 rb + ra (r* = bitrev4(k*)); q2 = qa + 16 qb + 256 qc.
 __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ coeffs, u64 *__restrict__ out,
                                                       const u64 *__restrict__ tw4096, const u64 *__restrict__ pre,
-                                                      const u64 *__restrict__ s_r, u64 w_n, int lg, int lgA, int R) {
+                                                      const u64 *__restrict__ s_r, u64 w_n, int lg, int lgA, int R, int lgAo) {
     __shared__ __attribute__((aligned(16))) u64 lds[R16_LDS];
     __shared__ u64 T0[64], T1[64], sk[MAXR_LDE];
     constexpr int B = 4096;
@@ -451,7 +515,8 @@ __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ co
         for (int rc = 0; rc < 16; rc++) x[rc] = lds[17 * tid + rc];      // step-3 role: tid = qa + 16 qb
         __syncthreads();
         dft16_dit<false>(x);                                 // over kc -> qc ; q2 = tid + 256 qc
-        u64 *dst = out + ((size_t)col * R + r) * n + (size_t)pb * B + tid;
+        // lgAo > 0: "col" is (column, outer block pbo); planes are laid out [column][r][pbo]
+        u64 *dst = out + (((((size_t)(col >> lgAo) * R + r) << lgAo) + (col & ((1u << lgAo) - 1))) * n) + (size_t)pb * B + tid;
         if (lgA > 0) {
             const u64 skr = sk[r];
 #pragma unroll
@@ -575,11 +640,31 @@ int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int l
     GLP_TRY(get_lde_plan(c, lg, rate_bits, shift, &lp));
     const NttPlan *np = lp->ntt;
     const int R = 1 << rate_bits;
-    if (ncols > 65535u || (u64)ncols * R > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols*2^rate_bits=%llu exceeds grid.y", (unsigned long long)ncols * R);
+    if (ncols > 65535u || ((u64)ncols * R << np->lgAo) > 65535u)
+        return set_error(GLP_ERR_UNSUPPORTED, "ncols*2^rate_bits*outer blocks=%llu exceeds grid.y", ((unsigned long long)ncols * R) << np->lgAo);
+    if (lg > NTT_2PASS_LG) {
+        // three passes: per 2^20 block the two-pass coset transform with shift^A', the outer twiddle, then A' rows at stride 2^20
+        const NttPlan *in = np->inner;
+        const LdePlan *lin = lp->inner;
+        const int lgAo = np->lgAo, lgM = NTT_2PASS_LG;
+        hipLaunchKernelGGL(k_lde_contig16, dim3(1u << in->lgA, ncols << lgAo), dim3(TPB), 0, c->stream, dev_coeffs, dev_lde, in->tw4096,
+                           lin->pre, lin->s_r, in->w_n, lgM, in->lgA, R, lgAo);
+        GLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<false>), dim3((1u << in->lgB) / NTT_STRIDED_W, (ncols * R) << lgAo), dim3(TPB), 0,
+                           c->stream, dev_lde, dev_lde, in->tw4096, lgM, in->lgB);
+        GLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_big_twiddle, dim3((1u << lgM) / 256, (ncols * R) << lgAo), dim3(256), 0, c->stream, dev_lde, lp->t0, lp->t1,
+                           lgAo, lgM, R);
+        GLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), dim3((1u << lgM) / NTT_STRIDED_W, ncols * R), dim3(TPB), 0, c->stream, dev_lde,
+                           dev_lde, np->tw_Ao, lg, lgAo, lgM);
+        GLP_HIP(hipGetLastError());
+        return GLP_OK;
+    }
     dim3 g1(1u << np->lgA, ncols);
     if (np->lgB == 12)
         hipLaunchKernelGGL(k_lde_contig16, g1, dim3(TPB), 0, c->stream, dev_coeffs, dev_lde, np->tw4096, lp->pre, lp->s_r,
-                           np->w_n, lg, np->lgA, R);
+                           np->w_n, lg, np->lgA, R, 0);
     else
         hipLaunchKernelGGL(k_lde_contig, g1, dim3(TPB), contig_lds_bytes(np->lgB), c->stream, dev_coeffs, dev_lde, np->tw_B,
                            lp->pre, lp->s_r, np->w_n, lg, np->lgA, np->lgB, R);
@@ -605,7 +690,24 @@ int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u3
     if (ncols == 0) return GLP_OK;
     NttPlan *np;
     GLP_TRY(get_ntt_plan(c, lg, &np));
-    if (ncols > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols=%u exceeds grid.y", ncols);
+    if (ncols > 65535u || ((u64)ncols << np->lgAo) > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols=%u exceeds grid.y", ncols);
+    if (lg > NTT_2PASS_LG) {
+        const NttPlan *in = np->inner;
+        const int lgAo = np->lgAo, lgM = NTT_2PASS_LG;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), dim3((1u << lgM) / NTT_STRIDED_W, ncols), dim3(TPB), 0, c->stream, dev_values,
+                           dev_coeffs, np->itw_Ao, lg, lgAo, lgM);
+        GLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_big_twiddle, dim3((1u << lgM) / 256, ncols << lgAo), dim3(256), 0, c->stream, dev_coeffs, np->it0, np->it1, lgAo,
+                           lgM, 1);
+        GLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<true>), dim3((1u << in->lgB) / NTT_STRIDED_W, ncols << lgAo), dim3(TPB), 0, c->stream,
+                           dev_coeffs, dev_coeffs, in->itw4096, lgM, in->lgB);
+        GLP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_intt_contig16, dim3(1u << in->lgA, ncols << lgAo), dim3(TPB), 0, c->stream, dev_coeffs, dev_coeffs, in->itw4096,
+                           in->w_n_inv, in->n_inv, lgM, in->lgA);
+        GLP_HIP(hipGetLastError());
+        return GLP_OK;
+    }
     const u64 *src = dev_values;
     if (np->lgA > 0) {
         dim3 g1((1u << np->lgB) / NTT_STRIDED_W, ncols);

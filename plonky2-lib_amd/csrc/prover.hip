@@ -1142,9 +1142,51 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         sum_ab += d.reduction_arity_bits[i];
         GLP_REQUIRE(sum_ab <= d.degree_bits && d.degree_bits + d.rate_bits - sum_ab >= d.cap_height, "FRI reduction deeper than the domain");
     }
+    // Shapes the quotient kernel assumes, checked here so that a malformed description is an error and never an
+    // out-of-bounds read on the device: wires / constants / constraints each gate type touches.
+    auto gate_shape = [](const glp_gate &g, u32 &wires, u32 &consts, u32 &constraints) -> bool {
+        const u32 p0 = g.p0, p1 = g.p1;
+        consts = 0;
+        switch (g.type) {
+        case GLP_GATE_NOOP: wires = 0; constraints = 0; return true;
+        case GLP_GATE_CONSTANT: wires = p0; consts = p0; constraints = p0; return true;
+        case GLP_GATE_PUBLIC_INPUT: wires = 4; constraints = 4; return true;
+        case GLP_GATE_ARITHMETIC: wires = 4 * p0; consts = 2; constraints = p0; return true;
+        case GLP_GATE_POSEIDON: wires = 135; constraints = 123; return true;
+        case GLP_GATE_U32_INTERLEAVE: wires = 34 * p0; constraints = 34 * p0; return true;
+        case GLP_GATE_UNINTERLEAVE_U32: case GLP_GATE_UNINTERLEAVE_B32: wires = 67 * p0; constraints = 67 * p0; return true;
+        case GLP_GATE_U32_ARITHMETIC: wires = 38 * p0; constraints = 36 * p0; return true;
+        case GLP_GATE_U32_ADD_MANY: wires = (p0 + 3 + 18) * p1; constraints = 21 * p1; return p0 >= 1 && p0 <= 16;
+        case GLP_GATE_U32_SUBTRACTION: wires = 21 * p0; constraints = 19 * p0; return true;
+        case GLP_GATE_U32_RANGE_CHECK: wires = 17 * p0; constraints = 17 * p0; return true;
+        case GLP_GATE_COMPARISON: {
+            if (p1 == 0 || p0 == 0 || p0 > 64) return false;
+            const u32 cb = (p0 + p1 - 1) / p1;
+            if (cb > 4) return false;
+            wires = 4 + 5 * p1 + cb + 1; constraints = 2 + 5 * p1 + 1 + (cb + 1) + 2; return true;
+        }
+        case GLP_GATE_BASE_SUM: wires = 1 + p0; constraints = 1 + p0; return p1 >= 2 && p1 <= 16;
+        case GLP_GATE_RANDOM_ACCESS: {
+            const u32 copies = p1 & 0xFFFF, nextra = p1 >> 16;
+            if (p0 < 1 || p0 > 5) return false;
+            wires = (2 + (1u << p0)) * copies + nextra + p0 * copies; consts = nextra; constraints = copies * (p0 + 2) + nextra;
+            return true;
+        }
+        default: return false;
+        }
+    };
     u32 maxc = 0;
     for (u32 i = 0; i < d.num_gates; i++) {
         const glp_gate &g = d.gates[i];
+        {
+            u32 gw = 0, gcn = 0, gk = 0;
+            if (!gate_shape(g, gw, gcn, gk))
+                return set_error(g.type > GLP_GATE_RANDOM_ACCESS ? GLP_ERR_UNSUPPORTED : GLP_ERR_ARG,
+                                 "gate %u: type %u with parameters (%u, %u) is not supported", i, g.type, g.p0, g.p1);
+            GLP_REQUIRE(gw <= d.num_wires, "gate %u (type %u) needs %u wires, circuit has %u", i, g.type, gw, d.num_wires);
+            GLP_REQUIRE(d.num_selectors + gcn <= d.num_constants, "gate %u (type %u) needs %u constants", i, g.type, gcn);
+            GLP_REQUIRE(gk == g.num_constraints, "gate %u (type %u): num_constraints %u, expected %u", i, g.type, g.num_constraints, gk);
+        }
         switch (g.type) {
         case GLP_GATE_NOOP: case GLP_GATE_CONSTANT: case GLP_GATE_PUBLIC_INPUT: case GLP_GATE_ARITHMETIC:
         case GLP_GATE_POSEIDON: if (g.type == GLP_GATE_POSEIDON && d.num_wires < 135) return set_error(GLP_ERR_ARG, "PoseidonGate needs 135 wires"); break;
@@ -1154,7 +1196,7 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         case GLP_GATE_RANDOM_ACCESS:
             GLP_REQUIRE(g.p0 >= 1 && g.p0 <= 5, "RandomAccessGate bits outside 1..5");
             break;
-        default: return set_error(GLP_ERR_UNSUPPORTED, "gate type %u is not built into the quotient kernel yet", g.type);
+        default: break;
         }
         GLP_REQUIRE(g.selector_index < d.num_selectors && g.group_start <= g.row && g.row < g.group_end, "bad selector data for gate %u", i);
         maxc = std::max(maxc, g.num_constraints);

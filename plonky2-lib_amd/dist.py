@@ -27,7 +27,7 @@ class Group:
             self.dist = None
 
 
-def init_from_env(use_cuda):
+def init_from_env(use_cuda, backend=None, force_device=None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets them."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -39,10 +39,12 @@ def init_from_env(use_cuda):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     device = None
+    backend = backend or ("nccl" if use_cuda else "gloo")
     if use_cuda:
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl" if use_cuda else "gloo", rank=rank, world_size=world)
+        d = local_rank if force_device is None else force_device
+        torch.cuda.set_device(d)
+        device = torch.device("cuda", d) if backend == "nccl" else None
+    dist.init_process_group(backend, rank=rank, world_size=world)
     return Group(rank, local_rank, world, dist, device)
 
 

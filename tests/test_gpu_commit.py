@@ -103,6 +103,33 @@ def test_batch_from_coeffs_parity(ctx, oracle, ncols, lg):
     b.free()
 
 
+@pytest.mark.parametrize("lg", [21, 22])
+def test_three_pass_transforms(ctx, oracle, lg):
+    """2^21 and 2^22 points: the outer strided pass over 2^20-point blocks."""
+    rng = np.random.default_rng(lg)
+    a = oracle.rand_field(rng, (2, 1 << lg))
+    f = ctx.fft(a)
+    assert (f[0] == oracle.fft(a[0])).all() and (f[1] == oracle.fft(a[1])).all()
+    i = ctx.ifft(a)
+    assert (i[1] == oracle.ifft(a[1])).all()
+    assert (ctx.ifft(f) == a).all()
+    if lg == 21:
+        got = ctx.lde(a[:1], 3, 7)
+        assert (got[0] == oracle.lde(a[0], 3, 7)).all()
+
+
+def test_three_pass_batch(ctx, oracle):
+    rng = np.random.default_rng(77)
+    vals = oracle.rand_field(rng, (5, 1 << 21))
+    ref = oracle.batch_from_values(vals, 3, 4)
+    b = ctx.batch_from_values(vals, 3, 4)
+    assert (b.cap() == ref.cap).all()
+    assert (b.coeffs(3, 1)[0] == ref.coeffs[3]).all()
+    for j in (0, 12345678, (1 << 24) - 1):
+        assert (b.leaf(j) == ref.leaves[j]).all() and (b.prove(j) == ref.prove(j)).all()
+    b.free()
+
+
 def test_golden_fixture(ctx):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_5x32.npz"))
@@ -143,5 +170,5 @@ def test_errors(ctx):
     with pytest.raises(glp.GlpError):
         ctx.batch_from_values(np.zeros((2, 12), np.uint64), 3, 1)     # not a power of two
     with pytest.raises(glp.GlpError) as e:
-        glp.Batch._make_dev(ctx, "glp_batch_from_values_device", 8, 1, 21, 3, 4)
+        glp.Batch._make_dev(ctx, "glp_batch_from_values_device", 8, 1, 25, 3, 4)      # > 2^24 rows
     assert e.value.code == -3

@@ -122,6 +122,20 @@ def test_prove_properties_2_16(ctx, oracle):
     assert oc.verify(bad) != 0
 
 
+def test_prove_2_21_rows_verifies(ctx, oracle):
+    """Past the two-pass NTT limit: 2^21 rows x 135 wires (three-pass transforms, 5 FRI reductions); the proof
+    must satisfy the oracle verifier (constants/sigmas cap taken from the circuit object)."""
+    desc = synth.arith_circuit(21, synth.Config.standard_recursion_config(), seed=21)
+    gc = glp.Circuit(ctx, desc)
+    proof = gc.prove()
+    desc.circuit_digest = gc.digest()
+    oc = oracle.OracleCircuit(desc, cs_cap=gc.constants_sigmas_cap())
+    assert oc.verify(proof) == 0
+    bad = proof.copy(); bad[5000] = np.uint64((int(bad[5000]) + 1) % glp.P)
+    assert oc.verify(bad) != 0
+    gc.free()
+
+
 def test_proof_bytes_roundtrip(ctx, oracle):
     desc = synth.arith_circuit(9, seed=21)
     gc = glp.Circuit(ctx, desc)
@@ -142,6 +156,20 @@ def test_proof_bytes_roundtrip(ctx, oracle):
     bad = bytearray(data); bad[q0] ^= 1
     with pytest.raises(glp.GlpError):
         gc.proof_from_bytes(bytes(bad))
+
+
+def test_malformed_gate_shapes_are_rejected_on_the_host(ctx):
+    """A description whose gates would read past the wire columns must fail in glp_circuit_create, not on the GPU."""
+    desc = synth.ecdsa_shape_circuit(7)
+    rc_gate = next(g for g in desc.gates if g["type"] == synth.GATE_U32_RANGE_CHECK)
+    rc_gate["p0"] = 9; rc_gate["num_constraints"] = 9 * 17          # 153 wires > 136
+    with pytest.raises(glp.GlpError) as e:
+        glp.Circuit(ctx, desc)
+    assert e.value.code == -1 and "wires" in str(e.value)
+    desc = synth.ecdsa_shape_circuit(7)
+    desc.gates[3]["num_constraints"] += 1
+    with pytest.raises(glp.GlpError):
+        glp.Circuit(ctx, desc)
 
 
 def test_unsupported_gate_is_reported(ctx):

@@ -76,6 +76,50 @@ __global__ void k_addc(u64 *out, u32 a, u32 b) {
     u32 s = 0; for (int i = 0; i < 8; i++) s ^= lo[i] ^ hi[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+__global__ void k_dot2(u64 *out, u32 a, u32 b) {
+    u32 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+    u32 x = a * 0x10001u + threadIdx.x, y = b | 0x00110017u;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y));
+    }
+    u32 s = 0; for (int i = 0; i < 8; i++) s ^= acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_dot4(u64 *out, u32 a, u32 b) {
+    u32 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+    u32 x = a * 0x01010101u + threadIdx.x, y = b | 0x11170f29u;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y));
+    }
+    u32 s = 0; for (int i = 0; i < 8; i++) s ^= acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_perm(u64 *out, u32 a, u32 b) {
+    u32 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+    u32 y = b + threadIdx.x, sel = 0x07060100u;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(y), "v"(sel));
+    }
+    u32 s = 0; for (int i = 0; i < 8; i++) s ^= acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mad24(u64 *out, u32 a, u32 b) {
+    u32 acc[8];
+    for (int i = 0; i < 8; i++) acc[i] = threadIdx.x + i + a;
+    u32 x = a + threadIdx.x, y = b | 17u;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(y));
+    }
+    u32 s = 0; for (int i = 0; i < 8; i++) s ^= acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ void k_mulmod(u64 *out, u64 a, u64 b) {
     u64 acc[4];
     for (int i = 0; i < 4; i++) acc[i] = glf::canon(a + threadIdx.x + i);
@@ -119,6 +163,10 @@ int main() {
     rep("v_add_u32", time_ms([&] { hipLaunchKernelGGL(k_add32, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
     rep("v_mul_lo_u32", time_ms([&] { hipLaunchKernelGGL(k_mullo, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
     rep("v_mul_hi_u32", time_ms([&] { hipLaunchKernelGGL(k_mulhi, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
+    rep("v_dot2_u32_u16", time_ms([&] { hipLaunchKernelGGL(k_dot2, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
+    rep("v_dot4_u32_u8", time_ms([&] { hipLaunchKernelGGL(k_dot4, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
+    rep("v_perm_b32", time_ms([&] { hipLaunchKernelGGL(k_perm, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
+    rep("v_mad_u32_u24", time_ms([&] { hipLaunchKernelGGL(k_mad24, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
     rep("v_mad_u64_u32", time_ms([&] { hipLaunchKernelGGL(k_mad64, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
     rep("v_lshl_add_u64", time_ms([&] { hipLaunchKernelGGL(k_lshladd64, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);
     rep("v_add_co+v_addc (pair)", time_ms([&] { hipLaunchKernelGGL(k_addc, dim3(blocks), dim3(threads), 0, 0, out, 1u, 3u); }), 8.0 * ITERS);

@@ -147,25 +147,20 @@ __device__ __forceinline__ u64 fold128_nc(u32 l0, u32 l1, u32 h0, u32 h1) {
     rhi = __builtin_addc(rhi, 0u, k2, &k2);
     return ((u64)rhi << 32) | rlo;
 }
-// l + 2^64 h, h < 2^32
+// l + 2^64 h, h < 2^32: one multiply-add by 2^32 - 1 and a carry fix-up (measured faster on gfx950 than the
+// 32-bit carry chain: profiles/r01_ubench_variants.txt)
 __device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
-    const u32 t1lo = 0u - h, t1hi = h - (h != 0);
-    u32 k, k2;
-    u32 rlo = __builtin_addc((u32)l, t1lo, 0u, &k);
-    u32 rhi = __builtin_addc((u32)(l >> 32), t1hi, k, &k);
-    const u32 m2 = 0u - k;
-    rlo = __builtin_addc(rlo, m2, 0u, &k2);
-    rhi = __builtin_addc(rhi, 0u, k2, &k2);
-    return ((u64)rhi << 32) | rlo;
+    u64 r = (u64)h * (u32)EPS + l;
+    if (r < l) r += EPS;
+    return r;
 }
-// any u64 inputs -> non-canonical product
+// any u64 inputs -> non-canonical product.  Two-level fold: x = lo + hi (2^32 - 1) as a 97-bit integer (no
+// conditional fix-ups), then fold96.
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 p00 = (u64)a0 * b0;
-    const u64 p01 = (u64)a0 * b1 + (p00 >> 32);
-    const u64 p10 = (u64)a1 * b0 + (u32)p01;
-    const u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
-    return fold128_nc((u32)p00, (u32)p10, (u32)p11, (u32)(p11 >> 32));
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    const u64 lo = (u64)p, hi = (u64)(p >> 64);
+    const unsigned __int128 y = (unsigned __int128)lo + ((unsigned __int128)hi << 32) - hi;
+    return fold96_nc((u64)y, (u32)(y >> 64));
 }
 // canonical product through the limb form
 __device__ __forceinline__ u64 mul_c(u64 a, u64 b) { return canon(mul_nc(a, b)); }

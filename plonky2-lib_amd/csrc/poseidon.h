@@ -96,17 +96,17 @@ __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
     for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        u64 al = (u32)rc[r], ah = rc[r] >> 32;
+        // low halves first; the high-half chain then starts from the low chain's overflow, so the 96-bit row value
+        // (ah : low 32 bits of al) needs no carry combine
+        u64 al = (u32)rc[r];
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
-            al += (u64)lo[(i + r) % 12] * C[i];
-            ah += (u64)hi[(i + r) % 12] * C[i];
-        }
-        if (r == 0) { al += (u64)lo[0] * 8; ah += (u64)hi[0] * 8; }
-        u32 k;
-        const u32 x1 = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &k);
-        const u32 h = (u32)(ah >> 32) + k;
-        s[r] = fold96_nc(((u64)x1 << 32) | (u32)al, h);
+        for (int i = 0; i < 12; i++) al += (u64)lo[(i + r) % 12] * C[i];
+        if (r == 0) al += (u64)lo[0] * 8;
+        u64 ah = (al >> 32) + (rc[r] >> 32);
+#pragma unroll
+        for (int i = 0; i < 12; i++) ah += (u64)hi[(i + r) % 12] * C[i];
+        if (r == 0) ah += (u64)hi[0] * 8;
+        s[r] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
     }
 }
 __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonical out

@@ -35,6 +35,21 @@ KERNEL(k_mullo_vc, ACC32, "v_mul_lo_u32 %0, %0, 17", "+v"(acc[i]) : )
 KERNEL(k_mul24_vc, ACC32, "v_mul_u32_u24 %0, %0, %1", "+v"(acc[i]) : "v"(y))
 KERNEL(k_lshladd64_vv, ACC64, "v_lshl_add_u64 %0, %0, 0, %1", "+v"(acc[i]) : "v"((u64)y))
 KERNEL(k_addco_sgpr, ACC32, "v_add_co_u32 %0, s[10:11], %0, %1", "+v"(acc[i]) : "v"(y) : "s10", "s11")
+KERNEL(k_mov, ACC32, "v_mov_b32 %0, %1", "+v"(acc[i]) : "v"(y))
+KERNEL(k_sub_vv, ACC32, "v_sub_u32 %0, %0, %1", "+v"(acc[i]) : "v"(y))
+KERNEL(k_and_vv, ACC32, "v_and_b32 %0, %0, %1", "+v"(acc[i]) : "v"(y))
+KERNEL(k_lshl_vc, ACC32, "v_lshlrev_b32 %0, 3, %0", "+v"(acc[i]) : )
+KERNEL(k_lshr_vc, ACC32, "v_lshrrev_b32 %0, 3, %0", "+v"(acc[i]) : )
+KERNEL(k_cndmask32, ACC32, "v_cndmask_b32 %0, %0, %1, vcc", "+v"(acc[i]) : "v"(y) : )
+KERNEL(k_cndmask64, ACC32, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]", "+v"(acc[i]) : "v"(y) : )
+KERNEL(k_cmp_u32, ACC32, "v_cmp_lt_u32 vcc, %0, %1", "+v"(acc[i]) : "v"(y) : "vcc")
+KERNEL(k_cmp_u64, ACC64, "v_cmp_lt_u64 vcc, %0, %1", "+v"(acc[i]) : "v"((u64)y) : "vcc")
+KERNEL(k_addco_vcc, ACC32, "v_add_co_u32 %0, vcc, %0, %1", "+v"(acc[i]) : "v"(y) : "vcc")
+KERNEL(k_addc_vcc, ACC32, "v_addc_co_u32 %0, vcc, %0, %1, vcc", "+v"(acc[i]) : "v"(y) : "vcc")
+KERNEL(k_alignbit, ACC32, "v_alignbit_b32 %0, %0, %1, 7", "+v"(acc[i]) : "v"(y))
+KERNEL(k_lshl64, ACC64, "v_lshlrev_b64 %0, 3, %0", "+v"(acc[i]) : )
+KERNEL(k_mov64, ACC64, "v_mov_b64 %0, %1", "+v"(acc[i]) : "v"((u64)y))
+KERNEL(k_or3, ACC32, "v_or3_b32 %0, %0, %1, %2", "+v"(acc[i]) : "v"(x), "v"(y))
 template <class F> static float time_ms(F launch) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     launch(); hipDeviceSynchronize();
@@ -51,5 +66,7 @@ int main() {
     RUN(k_add_vv) RUN(k_xor_vv) RUN(k_add3_vvv) RUN(k_add3_vsv) RUN(k_lshl_or) RUN(k_mad24_vvv) RUN(k_mad24_vcv) RUN(k_mad24_vsv)
     RUN(k_mul24_vc) RUN(k_dot2_vvv) RUN(k_dot2_vsv) RUN(k_dot4_vsv) RUN(k_perm_vvs) RUN(k_mad64_vvv) RUN(k_mad64_vcv) RUN(k_mad64_vsv)
     RUN(k_mullo_vc) RUN(k_lshladd64_vv) RUN(k_addco_sgpr)
+    RUN(k_mov) RUN(k_sub_vv) RUN(k_and_vv) RUN(k_lshl_vc) RUN(k_lshr_vc) RUN(k_cndmask32) RUN(k_cndmask64) RUN(k_cmp_u32) RUN(k_cmp_u64)
+    RUN(k_addco_vcc) RUN(k_addc_vcc) RUN(k_alignbit) RUN(k_lshl64) RUN(k_mov64) RUN(k_or3)
     return 0;
 }

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Issue-slot count of one Poseidon permutation, from the gfx950 ISA hipcc emits for csrc/merkle.hip.
-A slot = one full-rate VALU wave-instruction (2 cycles on a SIMD-32); v_mad_u64_u32, v_mul_{lo,hi}_u32,
-v_lshl_add_u64 and 64-bit shifts issue at half rate on gfx950 (profiles/r01_ubench_int_issue.txt) and
-count 2.  The permutation is three loops: 4 full rounds, 22 partial rounds, 4 full rounds; per-loop
+A slot = one full-rate VALU wave-instruction (2 cycles on a SIMD-32); per-opcode weights are calibrated by
+profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 2).  The permutation is three loops: 4 full rounds, 22 partial rounds, 4 full rounds; per-loop
 bodies are recognised by their multiply count.  Prints JSON."""
 import collections
 import json
@@ -13,7 +12,11 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HALF = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshlrev_b64", "v_lshrrev_b64", "v_mad_i64_i32"}
+# Measured on gfx950 (profiles/r01_ubench_opcode_rates.txt): only plain VOP2 add/sub/logic/mov/right-shift issue at
+# full rate; multiplies, multiply-adds, every carry-in/carry-out add, compares, selects with an SGPR mask, 64-bit
+# and three-operand forms issue at about half of it.
+FULL = {"v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_xor_b32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_mov_b32_e32",
+        "v_lshrrev_b32_e32", "v_not_b32_e32", "v_cndmask_b32_e32", "v_accvgpr_write_b32", "v_accvgpr_read_b32"}
 
 
 def main():
@@ -41,10 +44,12 @@ def main():
         if mads < 100:
             continue
         valu = sum(v for k, v in c.items() if k.startswith("v_"))
-        slots = sum(v * (2 if k in HALF else 1) for k, v in c.items() if k.startswith("v_"))
+        slots = sum(v * (1 if k in FULL else 2) for k, v in c.items() if k.startswith("v_"))
         res.append({"mads": mads, "valu_instructions": valu, "issue_slots": slots, "s_nop": c["s_nop"]})
-    full = [r for r in res if 400 <= r["mads"] <= 470]
-    part = [r for r in res if 200 <= r["mads"] <= 300]
+    # loop bodies: the partial round has the fewest multiplies; a full-round body has 11 more S-boxes
+    part_mads = min(r["mads"] for r in res)
+    part = [r for r in res if r["mads"] == part_mads]
+    full = [r for r in res if 1.4 * part_mads < r["mads"] < 2.6 * part_mads]
     per_full = min(r["issue_slots"] for r in full) if full else None
     per_part = min(r["issue_slots"] for r in part) if part else None
     out = {"loop_bodies": res, "full_round_slots": per_full, "partial_round_slots": per_part,

@@ -262,14 +262,21 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
     for (u32 chunk = 0; chunk < nchunks; chunk++) {
         u64 num[MAXCH], den[MAXCH];
         _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
-        const u32 j1 = min((chunk + 1) * a.qdf, a.nr);
-        for (u32 j = chunk * a.qdf; j < j1; j++) {
-            const u64 w = a.wl[(size_t)j * N + slot], s = a.cs[(size_t)(a.nc + j) * N + slot];
-            const u64 kx = mul(a.k_is[j], x);
-            _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-                num[c] = mul(num[c], add(add(w, mul(a.betas[c], kx)), a.gammas[c]));
-                den[c] = mul(den[c], add(add(w, mul(a.betas[c], s)), a.gammas[c]));
-            }
+        const u32 j0 = chunk * a.qdf, j1 = min((chunk + 1) * a.qdf, a.nr);
+        for (u32 jb = j0; jb < j1; jb += 8) {          // eight wire + eight sigma loads in flight
+            u64 w8[8], s8[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (jb + t < j1) { w8[t] = a.wl[(size_t)(jb + t) * N + slot]; s8[t] = a.cs[(size_t)(a.nc + jb + t) * N + slot]; }
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (jb + t < j1) {
+                    const u64 kx = mul(a.k_is[jb + t], x);
+                    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+                        num[c] = mul(num[c], add(add(w8[t], mul(a.betas[c], kx)), a.gammas[c]));
+                        den[c] = mul(den[c], add(add(w8[t], mul(a.betas[c], s8[t])), a.gammas[c]));
+                    }
+                }
         }
         _Pragma("unroll") for (int c = 0; c < NCH; c++) {
             const u64 prev = chunk == 0 ? zx[c] : a.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
@@ -298,6 +305,18 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
         const u64 _v = (v);                                                            \
         _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(ga[c2], _v, ap[c2 * nt + (k)]);       \
     } while (0)
+// Base-4 limb columns LIMBS[j*N], j = COUNT-1 .. 0: eight loads are issued before their values are used (the gate
+// loops have run-time bounds, so the compiler cannot software-pipeline them itself).  Constraint index KIDX may use _j.
+#define LIMBS4_DESC(LIMBS, COUNT, SPLIT, KIDX, ACCLO, ACCHI)                                                      \
+    for (int _j0 = (int)(COUNT); _j0 > 0; _j0 -= 8) {                                                             \
+        u64 _lv[8];                                                                                                \
+        _Pragma("unroll") for (int _t = 0; _t < 8; _t++) if (_t < _j0) _lv[_t] = (LIMBS)[(size_t)(_j0 - 1 - _t) * N]; \
+        _Pragma("unroll") for (int _t = 0; _t < 8; _t++) if (_t < _j0) {                                          \
+            const int _j = _j0 - 1 - _t;                                                                          \
+            EMIT((KIDX), range_product(_lv[_t], 4));                                                               \
+            if (_j < (int)(SPLIT)) ACCLO = add(dbl(dbl(ACCLO)), _lv[_t]); else ACCHI = add(dbl(dbl(ACCHI)), _lv[_t]); \
+        }                                                                                                         \
+    }
         switch (g.type) {
         case GLP_GATE_CONSTANT:
             for (u32 i = 0; i < g.p0; i++) EMIT(i, sub(GC[(size_t)i * N], W[(size_t)i * N]));
@@ -307,6 +326,7 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
             break;
         case GLP_GATE_ARITHMETIC: {
             const u64 c0 = GC[0], c1 = GC[N];
+#pragma unroll 4
             for (u32 i = 0; i < g.p0; i++) {
                 const u64 m0 = W[(size_t)(4 * i) * N], m1 = W[(size_t)(4 * i + 1) * N];
                 const u64 ad = W[(size_t)(4 * i + 2) * N], o = W[(size_t)(4 * i + 3) * N];
@@ -407,11 +427,8 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
                 EMIT(k, sub(add(mul(hi, (u64)1 << 32), lo), add(mul(m0, m1), ad))); k++;
                 u64 cl = 0, chh = 0;
                 const u64 *limbs = W + (size_t)(6 * nops + 32 * i) * N;
-                for (int j = 31; j >= 0; j--) {
-                    const u64 l = limbs[(size_t)j * N];
-                    EMIT(k, range_product(l, 4)); k++;
-                    if (j < 16) cl = add(dbl(dbl(cl)), l); else chh = add(dbl(dbl(chh)), l);
-                }
+                LIMBS4_DESC(limbs, 32, 16, k + (31 - _j), cl, chh);
+                k += 32;
                 EMIT(k, sub(cl, lo)); k++;
                 EMIT(k, sub(chh, hi)); k++;
             }
@@ -426,11 +443,8 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
                 EMIT(k, sub(add(mul(car, (u64)1 << 32), res), sum)); k++;
                 u64 cr = 0, cc = 0;
                 const u64 *limbs = W + (size_t)(wd * nops + 18 * i) * N;
-                for (int j = 17; j >= 0; j--) {
-                    const u64 l = limbs[(size_t)j * N];
-                    EMIT(k, range_product(l, 4)); k++;
-                    if (j < 16) cr = add(dbl(dbl(cr)), l); else cc = add(dbl(dbl(cc)), l);
-                }
+                LIMBS4_DESC(limbs, 18, 16, k + (17 - _j), cr, cc);
+                k += 18;
                 EMIT(k, sub(cr, res)); k++;
                 EMIT(k, sub(cc, car)); k++;
             }
@@ -442,9 +456,10 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
                 const u64 xx = W[(size_t)(5 * i) * N], yy = W[(size_t)(5 * i + 1) * N], bi = W[(size_t)(5 * i + 2) * N];
                 const u64 res = W[(size_t)(5 * i + 3) * N], bo = W[(size_t)(5 * i + 4) * N];
                 EMIT(k, sub(res, add(sub(sub(xx, yy), bi), mul(bo, (u64)1 << 32)))); k++;
-                u64 cl = 0;
+                u64 cl = 0, unused_hi = 0;
                 const u64 *limbs = W + (size_t)(5 * nops + 16 * i) * N;
-                for (int j = 15; j >= 0; j--) { const u64 l = limbs[(size_t)j * N]; EMIT(k, range_product(l, 4)); k++; cl = add(dbl(dbl(cl)), l); }
+                LIMBS4_DESC(limbs, 16, 16, k + (15 - _j), cl, unused_hi);
+                k += 16;
                 EMIT(k, sub(cl, res)); k++;
                 EMIT(k, mul(bo, sub(1, bo))); k++;
             }
@@ -454,10 +469,10 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
             u32 k = 0; const u32 nin = g.p0;
             for (u32 i = 0; i < nin; i++) {
                 const u64 *aux = W + (size_t)(nin + 16 * i) * N;
-                u64 sum = 0;
-                for (int j = 15; j >= 0; j--) sum = add(dbl(dbl(sum)), aux[(size_t)j * N]);
-                EMIT(k, sub(sum, W[(size_t)i * N])); k++;
-                for (int j = 0; j < 16; j++) { EMIT(k, range_product(aux[(size_t)j * N], 4)); k++; }
+                u64 sum = 0, unused_hi = 0;
+                LIMBS4_DESC(aux, 16, 16, k + 1 + _j, sum, unused_hi);
+                EMIT(k, sub(sum, W[(size_t)i * N]));
+                k += 17;
             }
             break;
         }
@@ -470,15 +485,25 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
             EMIT(k, sub(fa, W[0])); k++;
             EMIT(k, sub(fb, W[N])); k++;
             u64 msd = 0;
-            for (u32 i = 0; i < ncx; i++) {
-                const u64 ai = ca[(size_t)i * N], bi = cbp[(size_t)i * N], e = ceq[(size_t)i * N], inter = iv[(size_t)i * N];
-                EMIT(k, range_product(ai, cs)); k++;
-                EMIT(k, range_product(bi, cs)); k++;
-                const u64 diff = sub(bi, ai);
-                EMIT(k, sub(mul(diff, ed[(size_t)i * N]), sub(1, e))); k++;
-                EMIT(k, mul(e, diff)); k++;
-                EMIT(k, sub(inter, mul(e, msd))); k++;
-                msd = add(inter, mul(sub(1, e), diff));
+            for (u32 i0 = 0; i0 < ncx; i0 += 4) {     // 20 loads in flight per batch of four chunks
+                u64 la[4], lb[4], le[4], li[4], ld[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (i0 + t < ncx) {
+                        const size_t o = (size_t)(i0 + t) * N;
+                        la[t] = ca[o]; lb[t] = cbp[o]; le[t] = ceq[o]; li[t] = iv[o]; ld[t] = ed[o];
+                    }
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (i0 + t < ncx) {
+                        EMIT(k, range_product(la[t], cs)); k++;
+                        EMIT(k, range_product(lb[t], cs)); k++;
+                        const u64 diff = sub(lb[t], la[t]);
+                        EMIT(k, sub(mul(diff, ld[t]), sub(1, le[t]))); k++;
+                        EMIT(k, mul(le[t], diff)); k++;
+                        EMIT(k, sub(li[t], mul(le[t], msd))); k++;
+                        msd = add(li[t], mul(sub(1, le[t]), diff));
+                    }
             }
             const u64 msdw = W[(size_t)3 * N];
             EMIT(k, sub(msdw, msd)); k++;
@@ -534,6 +559,7 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
         }
         default: break;   // NOOP
         }
+#undef LIMBS4_DESC
 #undef EMIT
         _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc_reduce(ga[c])));
     }

@@ -102,6 +102,16 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64 *__restrict__ in
     store_digest(out + 4 * i, s);
 }
 
+// Small levels: one parent hash per 16-lane group (12 lanes active), 16 hashes per 256-thread workgroup.
+__global__ __launch_bounds__(256) void k_merkle_level_coop(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m) {
+    const int tid = threadIdx.x, l = tid & 15, lane = tid & 63, group_base = lane & ~15;
+    const size_t i = (size_t)blockIdx.x * 16 + (tid >> 4);
+    const bool live = i < m;
+    u64 x = (live && l < 8) ? in[8 * i + l] : 0;
+    x = pos::permute_coop(x, l, group_base);
+    if (live && l < 4) out[4 * i + l] = x;
+}
+
 __global__ void k_permute_states(u64 *states, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -113,13 +123,18 @@ __global__ void k_permute_states(u64 *states, size_t count) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
 }
 
+constexpr size_t MERKLE_COOP_MAX_PARENTS = 8192;
+
 static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height) {
     size_t w = nleaves, cap = (size_t)1 << cap_height;
     u64 *lvl = dev_digests;
     while (w > cap) {
         u64 *nxt = lvl + 4 * w;
         size_t m = w >> 1;
-        hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, lvl, nxt, m);
+        if (m <= MERKLE_COOP_MAX_PARENTS)   // few hashes: 12 lanes per hash for latency
+            hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, c->stream, lvl, nxt, m);
+        else
+            hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, lvl, nxt, m);
         GLP_HIP(hipGetLastError());
         lvl = nxt; w = m;
     }

@@ -238,60 +238,17 @@ struct QArgs {
     u64 betas[MAXCH], gammas[MAXCH], pih[4];
     u64 shift_r[MAXR], zh[MAXR], zh_inv[MAXR];   // per evaluated plane
     u64 w_n, n_field;
-    u32 lg, rb, step, nc, nsel, nr, nw, nch, npp, qdf, num_gates, nterms, many_selectors;
+    u32 lg, rb, step, nc, nsel, nr, nw, nch, npp, qdf, num_gates, nterms, many_selectors, gate_mode;
 };
-// K6: vanishing polynomial / Z_H on the planes r = 0, step, 2 step, ... of the coset-major LDE domain.
-//   terms: [L_0 (Z_c - 1)]_c, [prev*num - next*den]_{c,chunk}, gate constraints; res_c = sum_k term_k alpha_c^k
-template <int NCH>
-__global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
-    const size_t n = (size_t)1 << a.lg, N = n << a.rb;
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n) return;
-    const u32 rq = blockIdx.y, r = rq * a.step;
-    const size_t slot = (size_t)r * n + q, slot_next = (size_t)r * n + ((q + 1) & (n - 1));
-    const u64 x = mul(a.shift_r[rq], dpow(a.w_n, q));
-    constexpr u32 nch = NCH; const u32 nchunks = a.npp + 1, nt = a.nterms;
-    u64 acc[MAXCH], zx[MAXCH], zg[MAXCH];
-    Acc160 pa[MAXCH];
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) { acc_zero(pa[c]); zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
-    const u64 l0 = mul(a.zh[rq], inv(mul(a.n_field, sub(x, 1))));
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-        const u64 t = mul(l0, sub(zx[c], 1));
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + c]);
-    }
-    for (u32 chunk = 0; chunk < nchunks; chunk++) {
-        u64 num[MAXCH], den[MAXCH];
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
-        const u32 j0 = chunk * a.qdf, j1 = min((chunk + 1) * a.qdf, a.nr);
-        for (u32 jb = j0; jb < j1; jb += 8) {          // eight wire + eight sigma loads in flight
-            u64 w8[8], s8[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++)
-                if (jb + t < j1) { w8[t] = a.wl[(size_t)(jb + t) * N + slot]; s8[t] = a.cs[(size_t)(a.nc + jb + t) * N + slot]; }
-#pragma unroll
-            for (int t = 0; t < 8; t++)
-                if (jb + t < j1) {
-                    const u64 kx = mul(a.k_is[jb + t], x);
-                    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-                        num[c] = mul(num[c], add(add(w8[t], mul(a.betas[c], kx)), a.gammas[c]));
-                        den[c] = mul(den[c], add(add(w8[t], mul(a.betas[c], s8[t])), a.gammas[c]));
-                    }
-                }
-        }
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-            const u64 prev = chunk == 0 ? zx[c] : a.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
-            const u64 next = chunk == nchunks - 1 ? zg[c] : a.zl[(size_t)(nch + c * a.npp + chunk) * N + slot];
-            const u64 t = sub(mul(prev, num[c]), mul(next, den[c]));
-            const u32 k = nch + c * nchunks + chunk;
-            _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + k]);
-        }
-    }
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
-    const u32 k0 = nch + nch * nchunks;
+// Contribution of ONE gate at one point: filter(selector) * sum_k constraint_k * alpha_c^(k0 + k), added into acc[c].
+// TYPE >= 0 compiles a single gate body (per-gate kernels: small register footprint, high occupancy); TYPE = -1
+// keeps the run-time switch (monolithic fallback).
+template <int NCH, int TYPE>
+__device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
+    const u32 nt = a.nterms;
     const u64 *W = a.wl + slot;                       // wire j  -> W[j * N]
     const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
-    for (u32 gi = 0; gi < a.num_gates; gi++) {
-        const DevGate g = a.gates[gi];
+    {
         const u64 s = a.cs[(size_t)g.selector_index * N + slot];
         u64 filter = 1;
         for (u32 i = g.group_start; i < g.group_end; i++)
@@ -317,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
             if (_j < (int)(SPLIT)) ACCLO = add(dbl(dbl(ACCLO)), _lv[_t]); else ACCHI = add(dbl(dbl(ACCHI)), _lv[_t]); \
         }                                                                                                         \
     }
-        switch (g.type) {
+        switch (TYPE >= 0 ? (u32)TYPE : g.type) {   // TYPE >= 0: the switch folds to one case at compile time
         case GLP_GATE_CONSTANT:
             for (u32 i = 0; i < g.p0; i++) EMIT(i, sub(GC[(size_t)i * N], W[(size_t)i * N]));
             break;
@@ -563,8 +520,83 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
 #undef EMIT
         _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc_reduce(ga[c])));
     }
+}
+
+// K6: vanishing polynomial / Z_H on the planes r = 0, step, 2 step, ... of the coset-major LDE domain.
+//   terms: [L_0 (Z_c - 1)]_c, [prev*num - next*den]_{c,chunk}, gate constraints; res_c = sum_k term_k alpha_c^k
+template <int NCH>
+__global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
+    const size_t n = (size_t)1 << a.lg, N = n << a.rb;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u32 rq = blockIdx.y, r = rq * a.step;
+    const size_t slot = (size_t)r * n + q, slot_next = (size_t)r * n + ((q + 1) & (n - 1));
+    const u64 x = mul(a.shift_r[rq], dpow(a.w_n, q));
+    constexpr u32 nch = NCH; const u32 nchunks = a.npp + 1, nt = a.nterms;
+    u64 acc[MAXCH], zx[MAXCH], zg[MAXCH];
+    Acc160 pa[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) { acc_zero(pa[c]); zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
+    const u64 l0 = mul(a.zh[rq], inv(mul(a.n_field, sub(x, 1))));
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+        const u64 t = mul(l0, sub(zx[c], 1));
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + c]);
+    }
+    for (u32 chunk = 0; chunk < nchunks; chunk++) {
+        u64 num[MAXCH], den[MAXCH];
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
+        const u32 j0 = chunk * a.qdf, j1 = min((chunk + 1) * a.qdf, a.nr);
+        for (u32 jb = j0; jb < j1; jb += 8) {          // eight wire + eight sigma loads in flight
+            u64 w8[8], s8[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (jb + t < j1) { w8[t] = a.wl[(size_t)(jb + t) * N + slot]; s8[t] = a.cs[(size_t)(a.nc + jb + t) * N + slot]; }
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                if (jb + t < j1) {
+                    const u64 kx = mul(a.k_is[jb + t], x);
+                    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+                        num[c] = mul(num[c], add(add(w8[t], mul(a.betas[c], kx)), a.gammas[c]));
+                        den[c] = mul(den[c], add(add(w8[t], mul(a.betas[c], s8[t])), a.gammas[c]));
+                    }
+                }
+        }
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+            const u64 prev = chunk == 0 ? zx[c] : a.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
+            const u64 next = chunk == nchunks - 1 ? zg[c] : a.zl[(size_t)(nch + c * a.npp + chunk) * N + slot];
+            const u64 t = sub(mul(prev, num[c]), mul(next, den[c]));
+            const u32 k = nch + c * nchunks + chunk;
+            _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + k]);
+        }
+    }
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
+    const u32 k0 = nch + nch * nchunks;
+    if (a.gate_mode == 0) {                            // monolithic: every gate here
+        for (u32 gi = 0; gi < a.num_gates; gi++) {
+            const DevGate g = a.gates[gi];
+            gate_contrib<NCH, -1>(a, g, N, slot, k0, acc);
+        }
+    }
     const size_t Rq = (size_t)gridDim.y;
     _Pragma("unroll") for (int c = 0; c < NCH; c++) a.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
+}
+
+// One gate type per launch (gate_mode = 1): out[c][plane][q] += zh_inv * filter * sum_k constraint_k alpha_c^(k0 + k)
+template <int NCH, int TYPE>
+__global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, u32 gi) {
+    const size_t n = (size_t)1 << a.lg, N = n << a.rb;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u32 rq = blockIdx.y, r = rq * a.step;
+    const size_t slot = (size_t)r * n + q;
+    u64 acc[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
+    const DevGate g = a.gates[gi];
+    gate_contrib<NCH, TYPE>(a, g, N, slot, (u32)NCH + (u32)NCH * (a.npp + 1), acc);
+    const size_t Rq = (size_t)gridDim.y;
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+        u64 *o = a.out + ((size_t)c * Rq + rq) * n + q;
+        *o = add(*o, mul(acc[c], a.zh_inv[rq]));
+    }
 }
 
 // K6b: after the per-plane inverse NTT: undo the plane twist, inverse DFT across planes, undo the coset shift.
@@ -882,11 +914,30 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
         a.many_selectors = d.num_selectors > 1;
         {
             StageScope st(c, "quotient_eval", 8.0 * n * Rq * (nc + nr + nw + nzp + 2.0 * nch));
+            // two challenges (every preset the reference uses): permutation terms in one launch, then one launch per
+            // gate type compiled on its own; other challenge counts take the monolithic kernel
+            a.gate_mode = nch == 2 ? 1 : 0;
             switch (nch) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
             case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
             default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            }
+            GLP_HIP(hipGetLastError());
+            if (a.gate_mode == 1) {
+                for (u32 gi = 0; gi < d.num_gates; gi++) {
+#define GLP_GATE_LAUNCH(T) case T: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_gate<2, T>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, gi); break;
+                    switch (cc->gates[gi].type) {
+                        GLP_GATE_LAUNCH(GLP_GATE_CONSTANT) GLP_GATE_LAUNCH(GLP_GATE_PUBLIC_INPUT) GLP_GATE_LAUNCH(GLP_GATE_ARITHMETIC)
+                        GLP_GATE_LAUNCH(GLP_GATE_POSEIDON) GLP_GATE_LAUNCH(GLP_GATE_U32_INTERLEAVE) GLP_GATE_LAUNCH(GLP_GATE_UNINTERLEAVE_U32)
+                        GLP_GATE_LAUNCH(GLP_GATE_UNINTERLEAVE_B32) GLP_GATE_LAUNCH(GLP_GATE_U32_ARITHMETIC) GLP_GATE_LAUNCH(GLP_GATE_U32_ADD_MANY)
+                        GLP_GATE_LAUNCH(GLP_GATE_U32_SUBTRACTION) GLP_GATE_LAUNCH(GLP_GATE_U32_RANGE_CHECK) GLP_GATE_LAUNCH(GLP_GATE_COMPARISON)
+                        GLP_GATE_LAUNCH(GLP_GATE_BASE_SUM) GLP_GATE_LAUNCH(GLP_GATE_RANDOM_ACCESS)
+                    default: break;   // NoopGate: no constraints
+                    }
+#undef GLP_GATE_LAUNCH
+                    GLP_HIP(hipGetLastError());
+                }
             }
             GLP_HIP(hipGetLastError());
         }

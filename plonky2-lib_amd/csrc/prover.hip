@@ -524,8 +524,8 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
 
 // K6: vanishing polynomial / Z_H on the planes r = 0, step, 2 step, ... of the coset-major LDE domain.
 //   terms: [L_0 (Z_c - 1)]_c, [prev*num - next*den]_{c,chunk}, gate constraints; res_c = sum_k term_k alpha_c^k
-template <int NCH>
-__global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
+template <int NCH, bool WITH_GATES>
+__global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256, 3) void k_quotient(QArgs a) {
     }
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
     const u32 k0 = nch + nch * nchunks;
-    if (a.gate_mode == 0) {                            // monolithic: every gate here
+    if constexpr (WITH_GATES) {                        // monolithic: every gate here
         for (u32 gi = 0; gi < a.num_gates; gi++) {
             const DevGate g = a.gates[gi];
             gate_contrib<NCH, -1>(a, g, N, slot, k0, acc);
@@ -918,10 +918,10 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
             // gate type compiled on its own; other challenge counts take the monolithic kernel
             a.gate_mode = nch == 2 ? 1 : 0;
             switch (nch) {
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
-            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
-            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1, true>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, false>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3, true>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4, true>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
             }
             GLP_HIP(hipGetLastError());
             if (a.gate_mode == 1) {

@@ -470,9 +470,15 @@ __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ co
             sk[tid - 128] = dev_pow(s_r[tid - 128], k1);
         }
     }
-    // step-1 role: tid = 16 rc + rb, owns slots 16 tid .. 16 tid + 15 (ra = 0..15).  The 32-KB coefficient
-    // tile is re-read per coset (L2 hits) rather than held in 32 VGPRs across the coset loop.
-    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(coeffs + (size_t)col * n + (size_t)pb * B + 16 * tid);
+    // step-1 role: tid = 16 rc + rb, owns slots 16 tid .. 16 tid + 15 (ra = 0..15).  The coefficients are read from
+    // HBM once and held in 32 VGPRs across the coset loop (re-reading them per coset showed up as 7x the algorithmic
+    // fetch bytes in the FETCH_SIZE counter).
+    u64 c[16];
+    {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(coeffs + (size_t)col * n + (size_t)pb * B + 16 * tid);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const ulonglong2 v = src[e]; c[2 * e] = v.x; c[2 * e + 1] = v.y; }
+    }
     __syncthreads();
     const int hi4 = tid >> 4, lo4 = tid & 15;
     const int kb1_ = brev4(lo4);         // step 1: rb = lo4
@@ -489,9 +495,9 @@ __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ co
             const ulonglong2 *pr = reinterpret_cast<const ulonglong2 *>(pre + (size_t)r * B + 16 * tid);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const ulonglong2 v = pr[e], cc = src[e];
-                x[2 * e] = mul_c(cc.x, v.x);
-                x[2 * e + 1] = mul_c(cc.y, v.y);
+                const ulonglong2 v = pr[e];
+                x[2 * e] = mul_c(c[2 * e], v.x);
+                x[2 * e + 1] = mul_c(c[2 * e + 1], v.y);
             }
         }
         dft16_dit<false>(x);                                 // over ka -> qa

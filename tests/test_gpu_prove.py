@@ -56,6 +56,23 @@ def test_prove_parity_arith(ctx, oracle, lg, cfg):
     _check(ctx, oracle, desc)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(num_challenges=1),                                    # monolithic quotient kernel, one challenge
+    dict(num_challenges=3),                                    # ... three challenges
+    dict(max_quotient_degree_factor=4),                        # quotient on every second LDE plane (step 2), 19 partial products
+    dict(rate_bits=2, max_quotient_degree_factor=4),           # LDE x4
+    dict(rate_bits=4, cap_height=2, num_query_rounds=5),       # LDE x16, small cap
+    dict(proof_of_work_bits=0, num_query_rounds=1, cap_height=0),
+    dict(arity_bits=3, final_poly_bits=2, proof_of_work_bits=8),   # arity-8 FRI, more reductions
+    dict(arity_bits=1, final_poly_bits=3, num_query_rounds=3),     # arity-2 FRI: 4-element leaves are copied, not hashed
+])
+def test_prove_parity_config_sweep(ctx, oracle, kw):
+    """CircuitConfig / FriConfig fields away from the presets: every field the prover reads is honoured."""
+    config = synth.Config(135, 80, **kw)
+    desc = synth.arith_circuit(8, config, seed=31)
+    _check(ctx, oracle, desc)
+
+
 def test_prove_parity_public_inputs(ctx, oracle):
     pi = np.array([5, 6, 7, 8, 9], np.uint64)
     desc = synth.arith_circuit(7, seed=9, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi))

@@ -93,6 +93,27 @@ def test_batch_from_values_parity(ctx, oracle, ncols, lg, rb, ch):
     b.free()
 
 
+@pytest.mark.parametrize("ncols,lg,rb,ch", [
+    (1, 0, 3, 0),      # a single constant polynomial: n = 1
+    (5, 0, 3, 3),      # n = 1, cap = all 8 leaves
+    (2, 1, 1, 2),      # n = 2, LDE x2, cap height = log2(leaves)
+    (300, 4, 3, 4),    # many columns: 38 sponge absorptions per leaf, 2400 planes
+    (8, 7, 0, 3),      # rate_bits = 0: the "LDE" is the coset evaluation itself
+])
+def test_batch_edge_shapes(ctx, oracle, ncols, lg, rb, ch):
+    rng = np.random.default_rng(ncols * 31 + lg)
+    vals = oracle.rand_field(rng, (ncols, 1 << lg))
+    ref = oracle.batch_from_values(vals, rb, ch)
+    b = ctx.batch_from_values(vals, rb, ch)
+    _check_batch(oracle, b, ref, [0, 1, 3, (1 << (lg + rb)) - 1])
+    b.free()
+
+
+def test_empty_batch_is_an_error(ctx):
+    with pytest.raises(glp.GlpError):
+        ctx.batch_from_values(np.zeros((0, 8), np.uint64), 3, 2)
+
+
 @pytest.mark.parametrize("ncols,lg", [(16, 9), (7, 13)])
 def test_batch_from_coeffs_parity(ctx, oracle, ncols, lg):
     rng = np.random.default_rng(77 + lg)

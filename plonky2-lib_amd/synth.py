@@ -182,7 +182,7 @@ def _digits(v, base_bits, count):
     return [(v >> (base_bits * j)) & ((1 << base_bits) - 1) for j in range(count)]
 
 
-def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
+def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2, only=None):
     """Rows of the seven remaining gate types of the secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96]
     with the parameters `standard_ecc_config` gives them (136 wires / 80 routed / 2 constants), each with a
     satisfying witness built from the gate's definition.  Returns the next free row."""
@@ -191,9 +191,10 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
     M32 = (1 << 32) - 1
     ri = lambda hi: int(rng.integers(0, hi))
     row = first_row
+    want = lambda t: only is None or t in only
     # U32ArithmeticGate: m0*m1 + addend = out_hi 2^32 + out_lo
     n_ops = min(nr // 6, nw // 38)
-    for _ in range(rows_per_gate):
+    for _ in range(rows_per_gate if want(GATE_U32_ARITHMETIC) else 0):
         b.set_rows(np.array([row]), GATE_U32_ARITHMETIC, n_ops)
         for i in range(n_ops):
             m0, m1, ad = ri(1 << 32), ri(1 << 32), ri(1 << 32)
@@ -205,7 +206,7 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
     # U32AddManyGate, 3 addends
     na = 3
     n_ops = min(nr // (na + 3), nw // (na + 3 + 18))
-    for _ in range(rows_per_gate):
+    for _ in range(rows_per_gate if want(GATE_U32_ADD_MANY) else 0):
         b.set_rows(np.array([row]), GATE_U32_ADD_MANY, na, n_ops)
         for i in range(n_ops):
             vals = [ri(1 << 32) for _ in range(na + 1)]
@@ -219,7 +220,7 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
         row += 1
     # U32SubtractionGate
     n_ops = min(nr // 5, nw // 21)
-    for _ in range(rows_per_gate):
+    for _ in range(rows_per_gate if want(GATE_U32_SUBTRACTION) else 0):
         b.set_rows(np.array([row]), GATE_U32_SUBTRACTION, n_ops)
         for i in range(n_ops):
             x, y, bi = ri(1 << 32), ri(1 << 32), ri(2)
@@ -230,8 +231,8 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
             w[5 * n_ops + 16 * i:5 * n_ops + 16 * i + 16, row] = _digits(res, 2, 16)
         row += 1
     # U32RangeCheckGate, 8 limbs (exactly 136 wires)
-    n_in = 8
-    for _ in range(rows_per_gate):
+    n_in = min(8, nw // 17)
+    for _ in range(rows_per_gate if want(GATE_U32_RANGE_CHECK) else 0):
         b.set_rows(np.array([row]), GATE_U32_RANGE_CHECK, n_in)
         for i in range(n_in):
             v = ri(1 << 32)
@@ -241,7 +242,7 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
     # ComparisonGate(32 bits, 16 chunks)
     nbits, nch = 32, 16
     cb = nbits // nch
-    for k in range(rows_per_gate):
+    for k in range(rows_per_gate if want(GATE_COMPARISON) else 0):
         b.set_rows(np.array([row]), GATE_COMPARISON, nbits, nch)
         first, second = ri(1 << 32), ri(1 << 32)
         if k == 1:
@@ -266,7 +267,7 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
         assert bits[cb] == (1 if first <= second else 0)
         row += 1
     # BaseSumGate<4>, 16 limbs
-    for _ in range(rows_per_gate):
+    for _ in range(rows_per_gate if want(GATE_BASE_SUM) else 0):
         b.set_rows(np.array([row]), GATE_BASE_SUM, 16, 4)
         v = ri(1 << 32)
         w[0, row] = v
@@ -277,7 +278,7 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
     vs = 1 << bits_ra
     copies = min(nr // (2 + vs), nw // (2 + vs + bits_ra))
     nextra = min(nr - copies * (2 + vs), cfg.num_constants)
-    for _ in range(rows_per_gate):
+    for _ in range(rows_per_gate if want(GATE_RANDOM_ACCESS) else 0):
         b.set_rows(np.array([row]), GATE_RANDOM_ACCESS, bits_ra, copies | (nextra << 16))
         for c in range(copies):
             idx = ri(vs)
@@ -294,7 +295,7 @@ def fill_ecdsa_gate_rows(b, first_row, rows_per_gate=2):
 
 
 def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, num_const_rows=4, num_noop_rows=3,
-                  ecdsa_gate_rows=0):
+                  ecdsa_gate_rows=0, ecdsa_gate_subset=None, extra_rows=None):
     """ECDSA-shaped stand-in: one PublicInputGate row, a few ConstantGate rows, ArithmeticGate rows
     (20 ops wide for 80 routed wires) chained through copy constraints, NoopGate padding."""
     cfg = config or Config.standard_ecc_config()
@@ -308,13 +309,15 @@ def arith_circuit(log_n, config=None, seed=1, public_inputs=(), pi_hash=None, nu
             raise ValueError("pass pi_hash = hash_no_pad(public_inputs) when public inputs are non-empty")
         pi_hash = np.zeros(4, np.uint64)
     need_const_rows = max(num_const_rows, 2)
-    if n < 1 + need_const_rows + num_noop_rows + 2 + 7 * ecdsa_gate_rows:
+    if n < 1 + need_const_rows + num_noop_rows + 2 + 10 * ecdsa_gate_rows:
         raise ValueError("log_n too small")
     row_pi = 0
     rows_c = np.arange(1, 1 + need_const_rows)
     first_arith = 1 + need_const_rows
     if ecdsa_gate_rows:
-        first_arith = fill_ecdsa_gate_rows(b, first_arith, ecdsa_gate_rows)
+        first_arith = fill_ecdsa_gate_rows(b, first_arith, ecdsa_gate_rows, ecdsa_gate_subset)
+    if extra_rows is not None:
+        first_arith = extra_rows(b, first_arith)
     rows_a = np.arange(first_arith, n - num_noop_rows)
     b.set_rows(np.array([row_pi]), GATE_PUBLIC_INPUT, 0)
     b.set_rows(rows_c, GATE_CONSTANT, cfg.num_constants)
@@ -355,6 +358,53 @@ def ecdsa_shape_circuit(log_n, seed=3, rows_per_gate=2):
     its secp256k1 circuit [REF src/ecdsa/gadgets/ecdsa.rs:72-96] present (so the quotient kernel evaluates the
     same constraint set at every point, in three selector groups), ArithmeticGate rows filling the trace."""
     return arith_circuit(log_n, Config.standard_ecc_config(), seed=seed, ecdsa_gate_rows=rows_per_gate)
+
+
+def _fill_interleave_rows(b, row, rows_per_gate=2):
+    """Rows of the reference's three gates [REF src/u32/gates/*.rs] with satisfying witnesses."""
+    cfg = b.cfg
+    n_il = min(cfg.num_wires // 34, cfg.num_routed_wires // 2)
+    n_ul = min(cfg.num_wires // 67, cfg.num_routed_wires // 3)
+
+    def interleave(x):
+        r = 0
+        for i in range(32):
+            r |= ((x >> i) & 1) << (2 * i)
+        return r
+    for _ in range(rows_per_gate):
+        b.set_rows(np.array([row]), GATE_U32_INTERLEAVE, n_il)
+        for op in range(n_il):
+            x = int(b.rng.integers(0, 1 << 32))
+            b.wires[2 * op, row], b.wires[2 * op + 1, row] = x, interleave(x)
+            b.wires[2 * n_il + 32 * op:2 * n_il + 32 * op + 32, row] = [(x >> (31 - k)) & 1 for k in range(32)]
+        row += 1
+    for t in (GATE_UNINTERLEAVE_U32, GATE_UNINTERLEAVE_B32):
+        for _ in range(rows_per_gate):
+            b.set_rows(np.array([row]), t, n_ul)
+            for op in range(n_ul):
+                x, y = int(b.rng.integers(0, 1 << 31)), int(b.rng.integers(0, 1 << 31))
+                v = interleave(x) + interleave(y)
+                bits = [(v >> (63 - k)) & 1 for k in range(64)]
+                ev = sum(bits[2 * j] << (31 - j) for j in range(32))
+                od = sum(bits[2 * j + 1] << (31 - j) for j in range(32))
+                if t == GATE_UNINTERLEAVE_B32:
+                    ev, od = interleave(ev), interleave(od)
+                b.wires[3 * op:3 * op + 3, row] = [v, ev, od]
+                b.wires[3 * n_ul + 64 * op:3 * n_ul + 64 * op + 64, row] = bits
+            row += 1
+    return row
+
+
+def keccak_shape_circuit(log_n, seed=4, rows_per_gate=2):
+    """BASELINE configs 1 and 2 shape: `standard_recursion_config` (135 wires), the gate set SURVEY section 8 row Q
+    lists for the u32 / Keccak circuits -- U32Arithmetic, U32AddMany, U32Subtraction, the reference's own
+    U32Interleave / UninterleaveToU32 / UninterleaveToB32 [REF src/u32/interleaved_u32.rs:93-130], Constant,
+    Arithmetic, PublicInput, Noop -- with ArithmeticGate rows filling the trace.  (The Keccak-f1600 wiring itself
+    [REF src/hash/keccak256.rs:79-128] needs the Rust builder; the known-answer digests of that file pin the
+    witness generator, not the prover.)"""
+    return arith_circuit(log_n, Config.standard_recursion_config(), seed=seed, ecdsa_gate_rows=rows_per_gate,
+                         ecdsa_gate_subset=(GATE_U32_ARITHMETIC, GATE_U32_ADD_MANY, GATE_U32_SUBTRACTION),
+                         extra_rows=lambda b, row: _fill_interleave_rows(b, row, rows_per_gate))
 
 
 def u32_circuit(log_n=6, config=None, seed=2):

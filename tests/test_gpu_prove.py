@@ -97,6 +97,20 @@ def test_prove_parity_ecdsa_gate_set(ctx, oracle):
     _check(ctx, oracle, synth.ecdsa_shape_circuit(10, seed=8, rows_per_gate=5))
 
 
+def test_prove_parity_keccak_gate_set(ctx, oracle):
+    """BASELINE configs 1/2 gate set (u32 arithmetic gates + the reference's interleave gates), 135 wires."""
+    _check(ctx, oracle, synth.keccak_shape_circuit(7))
+
+
+def test_keccak_shape_2_15_verifies(ctx, oracle):
+    desc = synth.keccak_shape_circuit(15)
+    gc = glp.Circuit(ctx, desc)
+    proof = gc.prove()
+    desc.circuit_digest = gc.digest()
+    assert oracle.OracleCircuit(desc, cs_cap=gc.constants_sigmas_cap()).verify(proof) == 0
+    gc.free()
+
+
 def test_prove_parity_zkdsa_circuit(ctx, oracle):
     """BASELINE config 5: the simple-signature circuit, 2^3 rows, 4 PoseidonGate rows, 12 public inputs, two
     selector groups (PoseidonGate has degree 7)."""

@@ -102,6 +102,14 @@ def test_ecdsa_gate_set(oracle):
     assert oc.verify(bad) == 3
 
 
+def test_keccak_shape_circuit(oracle):
+    c = synth.keccak_shape_circuit(6)
+    assert sorted(g["type"] for g in c.gates) == [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+
+
 def test_fri_reduction_schedule():
     cfg = synth.Config.standard_ecc_config()
     assert cfg.reduction_arity_bits(20) == [4, 4, 4, 4]       # final polynomial of 16 coefficients

@@ -720,6 +720,27 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64 *vals, u64 *dig
     reinterpret_cast<ulonglong2 *>(digests + 4 * m)[0] = d0;
     reinterpret_cast<ulonglong2 *>(digests + 4 * m)[1] = d1;
 }
+// K9a, latency form for small layers: one leaf per 16-lane group, sponge state on 12 lanes.
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab) {
+    const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
+    const int tid = threadIdx.x, l = tid & 15, lane = tid & 63, group_base = lane & ~15;
+    const size_t Mp0 = (size_t)blockIdx.x * 16 + (tid >> 4);
+    const bool live = Mp0 < nleaves;
+    const size_t Mp = live ? Mp0 : 0;
+    const size_t m = bitrev32((u32)Mp, lgL - ab);
+    const u32 len = 2u << ab;                       // base-field elements per leaf
+    u64 x = 0;
+    for (u32 c = 0; c < len; c += 8) {
+        if (l < 8 && c + l < len) {
+            const u32 e = c + l, t = e >> 1;
+            const size_t i = (size_t)bitrev32(t, ab) * nleaves + Mp;
+            const size_t pos = (i & (((size_t)1 << rb) - 1)) * ncur + (i >> rb);
+            x = vals[(e & 1 ? L : 0) + pos];
+        }
+        if (len > 4) x = pos::permute_coop(x, l, group_base);
+    }
+    if (live && l < 4) digests[4 * m + l] = x;
+}
 // K9b: fold coefficients (bit-reversed layout): new[p'] = sum_t beta^t old[bitrev(t) * nnew + p']
 __global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ext2 beta, u32 lg_old, u32 ab) {
     const size_t nold = (size_t)1 << lg_old, nnew = nold >> ab;
@@ -1053,7 +1074,11 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
             GLP_TRY(tmp.get(&ly.vals, 2 * Lsz));
             GLP_TRY(tmp.get(&ly.dig, merkle_num_digests(nleaves, (int)d.cap_height) * 4));
             GLP_TRY(lde_coeffs(c, cur, ly.vals, 2, lgcur, rb, shift));
-            hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab);
+            if (nleaves <= 8192)
+                hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((nleaves + 15) / 16)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
+                                   (u32)rb, ab);
+            else
+                hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab);
             GLP_HIP(hipGetLastError());
             GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height));
             cap.resize((size_t)capn * 4);
@@ -1096,7 +1121,8 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
         a.best = (unsigned long long *)best;
         const u64 none = ~0ull;
         u64 found = none;
-        const u64 batch = 1ull << 20;
+        // expected 2^bits tries: size a launch at four times that (a 2^20-candidate launch is 0.6 ms of hashing)
+        const u64 batch = 1ull << std::min<u32>(20, std::max<u32>(14, d.proof_of_work_bits + 2));
         for (u64 base = 0; found == none; base += batch) {
             if (base >= (1ull << 40)) return set_error(GLP_ERR_PROVE, "Proof of work failed. This is highly unlikely!");
             GLP_TRY(h2d(c, best, &none, 8));

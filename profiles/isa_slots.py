@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Issue-slot count of one Poseidon permutation, from the gfx950 ISA hipcc emits for csrc/merkle.hip.
 A slot = one full-rate VALU wave-instruction (2 cycles on a SIMD-32); per-opcode weights are calibrated by
-profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 2).  The permutation is three loops: 4 full rounds, 22 partial rounds, 4 full rounds; per-loop
+profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 1.75).  The permutation is three loops: 4 full rounds, 22 partial rounds, 4 full rounds; per-loop
 bodies are recognised by their multiply count.  Prints JSON."""
 import collections
 import json
@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Measured on gfx950 (profiles/r01_ubench_opcode_rates.txt): only plain VOP2 add/sub/logic/mov/right-shift issue at
 # full rate; multiplies, multiply-adds, every carry-in/carry-out add, compares, selects with an SGPR mask, 64-bit
 # and three-operand forms issue at about half of it.
+HALF_WEIGHT = 1.75     # measured: ~57 vs ~100 lane-ops/clk/CU (profiles/r01_ubench_opcode_rates.txt)
 FULL = {"v_add_u32_e32", "v_sub_u32_e32", "v_subrev_u32_e32", "v_xor_b32_e32", "v_and_b32_e32", "v_or_b32_e32", "v_mov_b32_e32",
         "v_lshrrev_b32_e32", "v_not_b32_e32", "v_cndmask_b32_e32", "v_accvgpr_write_b32", "v_accvgpr_read_b32"}
 
@@ -44,7 +45,7 @@ def main():
         if mads < 100:
             continue
         valu = sum(v for k, v in c.items() if k.startswith("v_"))
-        slots = sum(v * (1 if k in FULL else 2) for k, v in c.items() if k.startswith("v_"))
+        slots = sum(v * (1.0 if k in FULL else HALF_WEIGHT) for k, v in c.items() if k.startswith("v_"))
         res.append({"mads": mads, "valu_instructions": valu, "issue_slots": slots, "s_nop": c["s_nop"]})
     # loop bodies: the partial round has the fewest multiplies; a full-round body has 11 more S-boxes
     part_mads = min(r["mads"] for r in res)

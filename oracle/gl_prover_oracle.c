@@ -476,24 +476,32 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
     {
         u64 w = gl_root_of_unity(lg);
         for (u32 i = 0; i < nch; i++) {
-            u64 z = 1, x = 1;
+            /* quotient_chunk_products per row (parallel over rows, as rayon does), then the running product */
+            u64 *qc_ = (u64 *)malloc((size_t)(npp + 1) * n * 8);
+#pragma omp parallel for schedule(static)
+            for (size_t row = 0; row < n; row++) {
+                u64 x = gl_pow(w, row);
+                for (u32 chunk = 0; chunk <= npp; chunk++) {
+                    u64 num = 1, den = 1;
+                    for (u32 j = chunk * qdf; j < (chunk + 1) * qdf && j < nr; j++) {
+                        u64 wv = wires[(size_t)j * n + row];
+                        num = gl_mul(num, gl_add(gl_add(wv, gl_mul(betas[i], gl_mul(c->k_is[j], x))), gammas[i]));
+                        den = gl_mul(den, gl_add(gl_add(wv, gl_mul(betas[i], c->sigmas[(size_t)j * n + row])), gammas[i]));
+                    }
+                    qc_[(size_t)chunk * n + row] = gl_mul(num, gl_inv(den));
+                }
+            }
+            u64 z = 1;
             for (size_t row = 0; row < n; row++) {
                 u64 acc = z;
                 zp[(size_t)i * n + row] = z; /* Z(x) */
                 for (u32 chunk = 0; chunk <= npp; chunk++) {
-                    u64 prod = 1;
-                    for (u32 j = chunk * qdf; j < (chunk + 1) * qdf && j < nr; j++) {
-                        u64 wv = wires[(size_t)j * n + row];
-                        u64 num = gl_add(gl_add(wv, gl_mul(betas[i], gl_mul(c->k_is[j], x))), gammas[i]);
-                        u64 den = gl_add(gl_add(wv, gl_mul(betas[i], c->sigmas[(size_t)j * n + row])), gammas[i]);
-                        prod = gl_mul(prod, gl_mul(num, gl_inv(den)));
-                    }
-                    acc = gl_mul(acc, prod);
+                    acc = gl_mul(acc, qc_[(size_t)chunk * n + row]);
                     if (chunk < npp) zp[((size_t)nch + (size_t)i * npp + chunk) * n + row] = acc;
                 }
                 z = acc; /* Z(g x) */
-                x = gl_mul(x, w);
             }
+            free(qc_);
         }
     }
     obatch zb; obatch_from_values(&zb, zp, nzp, c);
@@ -510,30 +518,33 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
         u64 wM = gl_root_of_unity(lg + qdb);
         u64 gn = gl_pow(GL_GEN, n);              /* ZeroPolyOnCoset: Z_H(g w^i) = g^n * w_rate^i - 1 */
         u64 wr = gl_root_of_unity(qdb);
-        gl2 *lc = (gl2 *)malloc(sizeof(gl2) * (nc + nr + nw + 4 * nzp + 16));
-        gl2 *sg = lc + nc, *lw = sg + nr, *zs = lw + nw, *zn = zs + nch, *pp = zn + nch;
-        u64 x = 1;
-        for (size_t i = 0; i < M; i++) {
-            u64 sx = gl_mul(GL_GEN, x);
-            const u64 *rc_ = lde_row(&cs, i, step, lgN);
-            const u64 *rw = lde_row(&wb, i, step, lgN);
-            const u64 *rz = lde_row(&zb, i, step, lgN);
-            const u64 *rzn = lde_row(&zb, (i + next_step) % M, step, lgN);
-            for (u32 k = 0; k < nc; k++) lc[k] = gl2_from(rc_[k]);
-            for (u32 k = 0; k < nr; k++) sg[k] = gl2_from(rc_[nc + k]);
-            for (u32 k = 0; k < nw; k++) lw[k] = gl2_from(rw[k]);
-            for (u32 k = 0; k < nch; k++) { zs[k] = gl2_from(rz[k]); zn[k] = gl2_from(rzn[k]); }
-            for (u32 k = 0; k < nch * npp; k++) pp[k] = gl2_from(rz[nch + k]);
-            u64 zh = gl_sub(gl_mul(gn, gl_pow(wr, i % next_step)), 1);
-            /* eval_l_0(i, x) = Z_H(x) / (n (x - 1)) */
-            u64 l0 = gl_mul(zh, gl_inv(gl_mul((u64)n % GL_P, gl_sub(sx, 1))));
-            gl2 res[8];
-            eval_vanishing(c, gl2_from(sx), gl2_from(l0), lc, lw, zs, zn, pp, sg, betas, gammas, alphas, pih, res);
-            u64 zhi = gl_inv(zh);
-            for (u32 k = 0; k < nch; k++) qv[(size_t)k * M + i] = gl_mul(res[k].a[0], zhi);
-            x = gl_mul(x, wM);
+        /* rayon's par_chunks over the points in the Rust prover; OpenMP over points here */
+#pragma omp parallel
+        {
+            gl2 *lc = (gl2 *)malloc(sizeof(gl2) * (nc + nr + nw + 4 * nzp + 16));
+            gl2 *sg = lc + nc, *lw = sg + nr, *zs = lw + nw, *zn = zs + nch, *pp = zn + nch;
+#pragma omp for schedule(static)
+            for (size_t i = 0; i < M; i++) {
+                u64 sx = gl_mul(GL_GEN, gl_pow(wM, i));
+                const u64 *rc_ = lde_row(&cs, i, step, lgN);
+                const u64 *rw = lde_row(&wb, i, step, lgN);
+                const u64 *rz = lde_row(&zb, i, step, lgN);
+                const u64 *rzn = lde_row(&zb, (i + next_step) % M, step, lgN);
+                for (u32 k = 0; k < nc; k++) lc[k] = gl2_from(rc_[k]);
+                for (u32 k = 0; k < nr; k++) sg[k] = gl2_from(rc_[nc + k]);
+                for (u32 k = 0; k < nw; k++) lw[k] = gl2_from(rw[k]);
+                for (u32 k = 0; k < nch; k++) { zs[k] = gl2_from(rz[k]); zn[k] = gl2_from(rzn[k]); }
+                for (u32 k = 0; k < nch * npp; k++) pp[k] = gl2_from(rz[nch + k]);
+                u64 zh = gl_sub(gl_mul(gn, gl_pow(wr, i % next_step)), 1);
+                /* eval_l_0(i, x) = Z_H(x) / (n (x - 1)) */
+                u64 l0 = gl_mul(zh, gl_inv(gl_mul((u64)n % GL_P, gl_sub(sx, 1))));
+                gl2 res[8];
+                eval_vanishing(c, gl2_from(sx), gl2_from(l0), lc, lw, zs, zn, pp, sg, betas, gammas, alphas, pih, res);
+                u64 zhi = gl_inv(zh);
+                for (u32 k = 0; k < nch; k++) qv[(size_t)k * M + i] = gl_mul(res[k].a[0], zhi);
+            }
+            free(lc);
         }
-        free(lc);
     }
     /* coset_ifft, trim_to_len(quotient_degree = qdf * n), chunks(n) */
     u64 *qc = (u64 *)malloc((size_t)nch * qdf * n * 8);
@@ -556,15 +567,23 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
 
     /* OpeningSet::new ; order of `to_fri_openings` zeta batch = constants, sigmas, wires, zs, pps, quotient */
     u64 *op = proof + L.openings;
-    size_t o = 0;
-    #define PUT(e) do { gl2 _e = (e); op[o++] = _e.a[0]; op[o++] = _e.a[1]; } while (0)
-    for (u32 k = 0; k < nc + nr; k++) PUT(eval_poly_ext(cs.coeffs + (size_t)k * n, n, zeta));
-    for (u32 k = 0; k < nw; k++) PUT(eval_poly_ext(wb.coeffs + (size_t)k * n, n, zeta));
-    for (u32 k = 0; k < nch; k++) PUT(eval_poly_ext(zb.coeffs + (size_t)k * n, n, zeta));
-    for (u32 k = 0; k < nch; k++) PUT(eval_poly_ext(zb.coeffs + (size_t)k * n, n, zeta_next));
-    for (u32 k = 0; k < nch * npp; k++) PUT(eval_poly_ext(zb.coeffs + (size_t)(nch + k) * n, n, zeta));
-    for (u32 k = 0; k < nch * qdf; k++) PUT(eval_poly_ext(qb.coeffs + (size_t)k * n, n, zeta));
-    #undef PUT
+    {
+        /* (coefficient pointer, point) per opened value, in `to_fri_openings` order; evaluated in parallel */
+        size_t cnt = L.nopen, o = 0;
+        const u64 **src = (const u64 **)malloc(cnt * sizeof(*src));
+        gl2 *pt = (gl2 *)malloc(cnt * sizeof(gl2));
+        #define PUT(ptr, z) do { src[o] = (ptr); pt[o] = (z); o++; } while (0)
+        for (u32 k = 0; k < nc + nr; k++) PUT(cs.coeffs + (size_t)k * n, zeta);
+        for (u32 k = 0; k < nw; k++) PUT(wb.coeffs + (size_t)k * n, zeta);
+        for (u32 k = 0; k < nch; k++) PUT(zb.coeffs + (size_t)k * n, zeta);
+        for (u32 k = 0; k < nch; k++) PUT(zb.coeffs + (size_t)k * n, zeta_next);
+        for (u32 k = 0; k < nch * npp; k++) PUT(zb.coeffs + (size_t)(nch + k) * n, zeta);
+        for (u32 k = 0; k < nch * qdf; k++) PUT(qb.coeffs + (size_t)k * n, zeta);
+        #undef PUT
+#pragma omp parallel for schedule(dynamic)
+        for (size_t k = 0; k < cnt; k++) { gl2 e = eval_poly_ext(src[k], n, pt[k]); op[2 * k] = e.a[0]; op[2 * k + 1] = e.a[1]; }
+        free(src); free(pt);
+    }
     /* observe_openings: batch zeta = [constants, sigmas, wires, zs, pps, quotient]; batch zeta_next = [zs_next] */
     {
         const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;

@@ -113,7 +113,7 @@ __device__ __forceinline__ u64 dpow(u64 b, u64 e) {
 
 struct PPArgs {
     const u64 *wires, *sigmas, *k_is;
-    u64 *zp;
+    u64 *zp, *dens;      // dens: scratch [nch][npp + 1][n]
     u64 betas[MAXCH], gammas[MAXCH];
     u64 w_n;
     u32 lg, nr, nch, npp, qdf;
@@ -125,8 +125,11 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const u64 x = dpow(a.w_n, i);
-    u64 cum[MAXCH];
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) cum[c] = 1;
+    // Pass 1: prefix products of the chunk numerators (into the output columns) and the chunk denominators
+    // (into `dens`); pass 2 walks back down with ONE field inversion per challenge instead of one per chunk:
+    // 1/PD_k = (1/PD_{k+1}) * den_{k+1}.
+    u64 pn[MAXCH], pd[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) { pn[c] = 1; pd[c] = 1; }
     for (u32 chunk = 0; chunk <= a.npp; chunk++) {
         u64 num[MAXCH], den[MAXCH];
         _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
@@ -140,9 +143,21 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
             }
         }
         _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-            cum[c] = mul(cum[c], mul(num[c], inv(den[c])));
+            pn[c] = mul(pn[c], num[c]);
+            pd[c] = mul(pd[c], den[c]);
             const u32 col = chunk < a.npp ? NCH + c * a.npp + chunk : c;   // Z column holds the row product for now
-            a.zp[(size_t)col * n + i] = cum[c];
+            a.zp[(size_t)col * n + i] = pn[c];
+            a.dens[((size_t)c * (a.npp + 1) + chunk) * n + i] = den[c];
+        }
+    }
+    u64 ipd[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) ipd[c] = inv(pd[c]);
+    for (int chunk = (int)a.npp; chunk >= 0; chunk--) {
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+            const u32 col = (u32)chunk < a.npp ? NCH + c * a.npp + chunk : c;
+            const size_t o = (size_t)col * n + i;
+            a.zp[o] = mul(a.zp[o], ipd[c]);
+            ipd[c] = mul(ipd[c], a.dens[((size_t)c * (a.npp + 1) + chunk) * n + i]);
         }
     }
 }
@@ -875,12 +890,14 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
     {
         u64 *zp, *tot;
         const u32 nblocks = nblk(n);
+        u64 *dens;
         GLP_TRY(tmp.get(&zp, (size_t)nzp * n));
+        GLP_TRY(tmp.get(&dens, (size_t)nzp * n));
         GLP_TRY(tmp.get(&tot, (size_t)nch * nblocks));
         {
             StageScope st(c, "partial_products", 8.0 * n * (2.0 * nr + nzp));
             PPArgs a;
-            a.wires = dev_wires; a.sigmas = cc->dev_sigmas; a.k_is = cc->dev_k_is; a.zp = zp;
+            a.wires = dev_wires; a.sigmas = cc->dev_sigmas; a.k_is = cc->dev_k_is; a.zp = zp; a.dens = dens;
             for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
             a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
             switch (nch) {

@@ -481,6 +481,11 @@ __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ co
     }
     __syncthreads();
     const int hi4 = tid >> 4, lo4 = tid & 15;
+    u64 postP[16];                       // (w_n^k1)^q2 for this thread's 16 outputs, shared by all cosets
+    if (lgA > 0) {
+#pragma unroll
+        for (int qc = 0; qc < 16; qc++) { const int q2 = tid + 256 * qc; postP[qc] = mul_nc(T1[q2 >> 6], T0[q2 & 63]); }
+    }
     const int kb1_ = brev4(lo4);         // step 1: rb = lo4
     const int kc2_ = brev4(lo4);         // step 2: rc = lo4, qa = hi4
     for (int r = 0; r < R; r++) {
@@ -526,10 +531,7 @@ __global__ __launch_bounds__(TPB) void k_lde_contig16(const u64 *__restrict__ co
         if (lgA > 0) {
             const u64 skr = sk[r];
 #pragma unroll
-            for (int qc = 0; qc < 16; qc++) {
-                const int q2 = tid + 256 * qc;
-                dst[256 * qc] = mul_c(x[qc], mul_nc(mul_nc(T1[q2 >> 6], T0[q2 & 63]), skr));
-            }
+            for (int qc = 0; qc < 16; qc++) dst[256 * qc] = mul_c(x[qc], mul_nc(postP[qc], skr));
         } else {
 #pragma unroll
             for (int qc = 0; qc < 16; qc++) dst[256 * qc] = x[qc];

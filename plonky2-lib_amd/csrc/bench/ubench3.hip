@@ -70,6 +70,19 @@ __device__ __forceinline__ u64 sqr_v2(u64 a, u64) {
     unsigned __int128 y = (unsigned __int128)lo + ((unsigned __int128)hi << 32) - hi;
     return fold96_v2((u64)y, (u32)(y >> 64));
 }
+// V5: fold96 with the multiply-add's own carry-out (inline asm: hipcc has no builtin for the carry of v_mad_u64_u32)
+__device__ __forceinline__ u64 fold96_asm(u64 l, u32 h) {
+    u64 r; u32 m;
+    asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, vcc"
+                 : "=&v"(r), "=v"(m) : "v"(h), "s"(0xFFFFFFFFu), "v"(l) : "vcc");
+    return r + (u64)m;
+}
+__device__ __forceinline__ u64 mul_v5(u64 a, u64 b) {
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    const u64 lo = (u64)p, hi = (u64)(p >> 64);
+    const unsigned __int128 y = (unsigned __int128)lo + ((unsigned __int128)hi << 32) - hi;
+    return fold96_asm((u64)y, (u32)(y >> 64));
+}
 #define MULK(NAME, F)                                                                 \
     __global__ void NAME(u64 *out, u64 a, u64 b) {                                    \
         u64 acc[4];                                                                   \
@@ -85,6 +98,7 @@ MULK(k_mul_v1, mul_v1)
 MULK(k_mul_v2, mul_v2)
 MULK(k_mul_v3, mul_v3)
 MULK(k_sqr_v2, sqr_v2)
+MULK(k_mul_v5, mul_v5)
 
 // MDS row variants: 12 rows of 24 multiply-adds + fold
 template <int V> __device__ __forceinline__ void mds_v(u64 s[12], const u64 *rc) {
@@ -98,7 +112,7 @@ template <int V> __device__ __forceinline__ void mds_v(u64 s[12], const u64 *rc)
 #pragma unroll
         for (int i = 0; i < 12; i++) { al += (u64)lo[(i + r) % 12] * C[i]; ah += (u64)hi[(i + r) % 12] * C[i]; }
         if (r == 0) { al += (u64)lo[0] * 8; ah += (u64)hi[0] * 8; }
-        if (V == 2 || V == 3) {
+        if (V == 2 || V == 3 || V == 4) {
             // chained: the high-half chain starts from the low half's overflow, so the 96-bit value needs no carry combine
             u64 al2 = (u32)rc[r];
 #pragma unroll
@@ -110,7 +124,7 @@ template <int V> __device__ __forceinline__ void mds_v(u64 s[12], const u64 *rc)
             if (r == 0) ah2 += (u64)hi[0] * 8;
             const u64 l = (ah2 << 32) | (u32)al2;
             const u32 h = (u32)(ah2 >> 32);
-            s[r] = V == 2 ? fold96_v2(l, h) : fold96_nc(l, h);
+            s[r] = V == 2 ? fold96_v2(l, h) : (V == 3 ? fold96_nc(l, h) : fold96_asm(l, h));
         } else if (V == 0) {
             u32 k;
             const u32 x1 = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &k);
@@ -145,7 +159,7 @@ int main() {
     double lanes = (double)blocks * threads;
 #define RUNM(K) { float ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, out, (u64)12345, (u64)0xfedcba9876543210ull); }); \
                   printf("%-10s %7.3f ms  %7.1f lane-clk per mulmod\n", #K, ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 4.0 * ITERS)); }
-    RUNM(k_mul_v0) RUNM(k_mul_v1) RUNM(k_mul_v2) RUNM(k_mul_v3) RUNM(k_sqr_v2)
+    RUNM(k_mul_v0) RUNM(k_mul_v1) RUNM(k_mul_v2) RUNM(k_mul_v3) RUNM(k_sqr_v2) RUNM(k_mul_v5)
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<0>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });
       printf("k_mds<0>   %7.3f ms  %7.1f lane-clk per MDS layer\n", ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 256.0)); }
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<1>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });
@@ -154,5 +168,7 @@ int main() {
       printf("k_mds<2>   %7.3f ms  %7.1f lane-clk per MDS layer\n", ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 256.0)); }
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<3>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });
       printf("k_mds<3>   %7.3f ms  %7.1f lane-clk per MDS layer\n", ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 256.0)); }
+    { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<4>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });
+      printf("k_mds<4>   %7.3f ms  %7.1f lane-clk per MDS layer\n", ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 256.0)); }
     return 0;
 }

@@ -148,11 +148,25 @@ __device__ __forceinline__ u64 fold128_nc(u32 l0, u32 l1, u32 h0, u32 h1) {
     return ((u64)rhi << 32) | rlo;
 }
 // l + 2^64 h, h < 2^32: one multiply-add by 2^32 - 1 and a carry fix-up (measured faster on gfx950 than the
-// 32-bit carry chain: profiles/r01_ubench_variants.txt)
-__device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
+// 32-bit carry chain: profiles/r01_ubench_variants.txt).  The carry is the v_mad_u64_u32's own carry-out, which
+// hipcc has no builtin for (from C it re-derives it with a 64-bit compare and two selects: 6 VALU slots against
+// 3 here); the s_nop covers the VCC write -> v_cndmask read hazard the compiler cannot see inside an asm block.
+__device__ __forceinline__ u64 fold96_c(u64 l, u32 h) {   // plain-C form (lower register pressure under hipcc's scheduler)
     u64 r = (u64)h * (u32)EPS + l;
     if (r < l) r += EPS;
     return r;
+}
+__device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r, cc; u32 m;
+    asm("v_mad_u64_u32 %0, %2, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %1, 0, -1, %2"
+        : "=v"(r), "=v"(m), "=&s"(cc) : "v"(h), "v"(l));
+    return r + (u64)m;       // carry: add 2^64 mod p = 2^32 - 1 (cannot carry again: r < h (2^32 - 1) then)
+#else
+    u64 r = (u64)h * (u32)EPS + l;
+    if (r < l) r += EPS;
+    return r;
+#endif
 }
 // any u64 inputs -> non-canonical product.  Two-level fold: x = lo + hi (2^32 - 1) as a 97-bit integer (no
 // conditional fix-ups), then fold96.

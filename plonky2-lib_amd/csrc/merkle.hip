@@ -36,7 +36,7 @@ __device__ __forceinline__ void store_digest(u64 *dst, const u64 s[12]) {
 }
 
 // hash_or_noop of one LDE row per lane.  grid.x * 256 >= N
-__global__ __launch_bounds__(256) void k_leaf_hash_lde(const u64 *__restrict__ lde, u64 *__restrict__ digests,
+__global__ __launch_bounds__(256, 4) void k_leaf_hash_lde(const u64 *__restrict__ lde, u64 *__restrict__ digests,
                                                        u32 ncols, int lg, int rate_bits) {
     const size_t N = (size_t)1 << (lg + rate_bits);
     const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_leaf_hash_lde_coop(const u64 *__restric
 }
 
 // hash_or_noop of row-major leaves [nleaves][leaf_len]
-__global__ __launch_bounds__(256) void k_leaf_hash_rows(const u64 *__restrict__ rows, u64 *__restrict__ digests,
+__global__ __launch_bounds__(256, 4) void k_leaf_hash_rows(const u64 *__restrict__ rows, u64 *__restrict__ digests,
                                                         size_t nleaves, u32 leaf_len) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= nleaves) return;

@@ -88,6 +88,21 @@ __device__ __forceinline__ u64 sbox7_nc(u64 x) {
     const u64 x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
     return mul_nc(x3, x4);
 }
+// 12 S-boxes in groups of SBOX_GROUP: the scheduling barrier keeps hipcc from interleaving all 12 chains (which
+// costs ~50 VGPRs and a wave of occupancy); within a group the chains still overlap
+#ifndef GLP_MDS_GROUP
+#define GLP_MDS_GROUP 4
+#endif
+#ifndef GLP_SBOX_GROUP
+#define GLP_SBOX_GROUP 4
+#endif
+__device__ __forceinline__ void sbox_layer_nc(u64 s[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        s[i] = sbox7_nc(s[i]);
+        if (i % GLP_SBOX_GROUP == GLP_SBOX_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
 // s <- MDS * s + rc   (rc = the NEXT round's constants), inputs and outputs non-canonical
 __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -106,7 +121,12 @@ __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
 #pragma unroll
         for (int i = 0; i < 12; i++) ah += (u64)hi[(i + r) % 12] * C[i];
         if (r == 0) ah += (u64)hi[0] * 8;
+#ifdef GLP_MDS_FOLD_C
+        s[r] = fold96_c((ah << 32) | (u32)al, (u32)(ah >> 32));
+#else
         s[r] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
+#endif
+        if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonical out
@@ -114,8 +134,7 @@ __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonic
     for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[i]);
     int rc = 12;
     for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7_nc(s[i]);
+        sbox_layer_nc(s);
         mds_add_nc(s, RC + rc);
         rc += 12;
     }
@@ -125,13 +144,11 @@ __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonic
         rc += 12;
     }
     for (int r = 0; r < 3; r++) {
-#pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = sbox7_nc(s[i]);
+        sbox_layer_nc(s);
         mds_add_nc(s, RC + rc);
         rc += 12;
     }
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = sbox7_nc(s[i]);
+    sbox_layer_nc(s);
     mds_add_nc(s, RC_ZERO);
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = canon(s[i]);

@@ -83,6 +83,19 @@ __device__ __forceinline__ u64 mul_v5(u64 a, u64 b) {
     const unsigned __int128 y = (unsigned __int128)lo + ((unsigned __int128)hi << 32) - hi;
     return fold96_asm((u64)y, (u32)(y >> 64));
 }
+// V6: the 97-bit y = lo + hi (2^32 - 1) from two more multiply-adds (carry-out of the first fed to the top limb)
+// instead of a 128-bit shift/sub/add carry chain
+__device__ __forceinline__ u64 mul_v6(u64 a, u64 b) {
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    const u64 lo = (u64)p, hi = (u64)(p >> 64);
+    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t, cc;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cc) : "v"(h0), "v"(lo));
+    const u64 u = (u64)h1 * 0xFFFFFFFFu + (t >> 32);
+    u32 h; const u32 ulo = (u32)u, uhi = (u32)(u >> 32);
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(h), "+s"(cc) : "v"(uhi));
+    return fold96_asm(((u64)ulo << 32) | (u32)t, h);
+}
 #define MULK(NAME, F)                                                                 \
     __global__ void NAME(u64 *out, u64 a, u64 b) {                                    \
         u64 acc[4];                                                                   \
@@ -99,6 +112,7 @@ MULK(k_mul_v2, mul_v2)
 MULK(k_mul_v3, mul_v3)
 MULK(k_sqr_v2, sqr_v2)
 MULK(k_mul_v5, mul_v5)
+MULK(k_mul_v6, mul_v6)
 
 // MDS row variants: 12 rows of 24 multiply-adds + fold
 template <int V> __device__ __forceinline__ void mds_v(u64 s[12], const u64 *rc) {
@@ -158,8 +172,9 @@ int main() {
     u64 *out, *rc; hipMalloc(&out, (size_t)blocks * threads * 8); hipMalloc(&rc, 96); hipMemset(rc, 1, 96);
     double lanes = (double)blocks * threads;
 #define RUNM(K) { float ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, out, (u64)12345, (u64)0xfedcba9876543210ull); }); \
-                  printf("%-10s %7.3f ms  %7.1f lane-clk per mulmod\n", #K, ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 4.0 * ITERS)); }
-    RUNM(k_mul_v0) RUNM(k_mul_v1) RUNM(k_mul_v2) RUNM(k_mul_v3) RUNM(k_sqr_v2) RUNM(k_mul_v5)
+                  u64 h4[4]; hipMemcpy(h4, out + 1000, 32, hipMemcpyDeviceToHost); \
+                  printf("%-10s %7.3f ms  %7.1f lane-clk per mulmod   check %016llx\n", #K, ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 4.0 * ITERS), (unsigned long long)(h4[0] ^ h4[1] * 3 ^ h4[2] * 5 ^ h4[3] * 7)); }
+    RUNM(k_mul_v0) RUNM(k_mul_v1) RUNM(k_mul_v2) RUNM(k_mul_v3) RUNM(k_mul_v5) RUNM(k_mul_v6)
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<0>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });
       printf("k_mds<0>   %7.3f ms  %7.1f lane-clk per MDS layer\n", ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 256.0)); }
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<1>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });

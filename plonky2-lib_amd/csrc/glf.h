@@ -168,13 +168,27 @@ __device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
     return r;
 #endif
 }
-// any u64 inputs -> non-canonical product.  Two-level fold: x = lo + hi (2^32 - 1) as a 97-bit integer (no
-// conditional fix-ups), then fold96.
+// any u64 inputs -> non-canonical product.  Two-level fold: y = lo + hi (2^32 - 1) as a 97-bit integer, then
+// fold96.  y itself comes from two more multiply-adds by 2^32 - 1 (hi = h0 + 2^32 h1):
+//     t + 2^64 c = h0 (2^32-1) + lo,    u = h1 (2^32-1) + (t >> 32)  (< 2^64),    y = t_lo + 2^32 u_lo + 2^64 (u_hi + c)
+// which costs 3 half-rate VALU slots + 1 move against the 6 carry-chain slots of a 128-bit shift/sub/add
+// (profiles/r01_ubench_variants.txt: 35.9 -> 32.5 lane-clk).  The carry c travels in an SGPR pair; the s_nop
+// covers the VALU-writes-SGPR -> VALU-reads-SGPR hazard the compiler cannot see across asm blocks.
 __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
     const unsigned __int128 p = (unsigned __int128)a * b;
     const u64 lo = (u64)p, hi = (u64)(p >> 64);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t, cc;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(cc) : "v"(h0), "v"(lo));
+    const u64 u = (u64)h1 * 0xFFFFFFFFu + (t >> 32);
+    u32 h;
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(h), "+s"(cc) : "v"((u32)(u >> 32)));
+    return fold96_nc((u << 32) | (u32)t, h);
+#else
     const unsigned __int128 y = (unsigned __int128)lo + ((unsigned __int128)hi << 32) - hi;
     return fold96_nc((u64)y, (u32)(y >> 64));
+#endif
 }
 // canonical product through the limb form
 __device__ __forceinline__ u64 mul_c(u64 a, u64 b) { return canon(mul_nc(a, b)); }

@@ -129,6 +129,130 @@ __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
         if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
+// ---- partial rounds, K at a time -------------------------------------------------------------------
+// A partial round is x <- M (E x + e0 sbox(x0)) + c  (E zeroes coordinate 0, c = the next round's constants):
+// linear except for ONE S-box, so K of them compose into
+//     z_j = A_j v + sum_{i=2..j} B_{j-i} sigma_i + Kc_j,     v = [sigma_1; x_1..x_11],  sigma_{j+1} = sbox(z_j[0]),
+//     A_1 = M, A_j = M E A_{j-1};  B_0 = M[:,0], B_t = M E B_{t-1};  Kc_1 = c_1, Kc_j = M E Kc_{j-1} + c_j
+// and only z_K is needed in full: rows 0 of A_1..A_{K-1} (24 multiply-adds each) plus ONE 12-row product with
+// A_K instead of K of them.  The entries stay small integers (A_4 < 2^29, row weight < 2^31.8), so the same
+// unreduced 32-bit-limb accumulation + single fold as the plain MDS layer applies: 438 v_mad_u64_u32 per 4
+// rounds instead of 1152.  (plonky2's own "fast partial round" form reaches fewer multiplications but with
+// full-width field constants, which on gfx950 costs more issue slots than this: profiles/r01_ubench_variants.txt.)
+// Same permutation: tests/test_gpu_commit.py checks it against the oracle's naive schedule.
+namespace pblk {
+constexpr u64 PRIME = 0xFFFFFFFF00000001ULL;
+constexpr u32 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+constexpr u64 RC_CE[360] = { GLP_POSEIDON_RC_LIST };
+constexpr u64 m_at(int r, int c) { return CIRC[(c - r + 12) % 12] + ((r == 0 && c == 0) ? 8u : 0u); }
+template <int K> struct Tab {
+    u32 a0[K][12] = {};      // a0[j-1] = row 0 of A_j           (j = 1..K-1 used)
+    u32 aK[12][12] = {};     // A_K
+    u32 bt[K][12] = {};      // B_t, t = 0..K-2 used
+    u64 max_weight = 0;      // largest total coefficient weight of one output (overflow bound)
+};
+template <int K> constexpr Tab<K> make_tab() {
+    Tab<K> t{};
+    u64 A[12][12] = {}, N[12][12] = {};
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) A[r][c] = m_at(r, c);
+    for (int c = 0; c < 12; c++) t.a0[0][c] = (u32)A[0][c];
+    for (int j = 2; j <= K; j++) {
+        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {
+            u64 acc = 0;
+            for (int k = 1; k < 12; k++) acc += m_at(r, k) * A[k][c];
+            N[r][c] = acc;
+        }
+        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) A[r][c] = N[r][c];
+        if (j < K) for (int c = 0; c < 12; c++) t.a0[j - 1][c] = (u32)A[0][c];
+    }
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) t.aK[r][c] = (u32)A[r][c];
+    for (int r = 0; r < 12; r++) t.bt[0][r] = (u32)m_at(r, 0);
+    for (int s = 1; s < K; s++)
+        for (int r = 0; r < 12; r++) {
+            u64 acc = 0;
+            for (int k = 1; k < 12; k++) acc += m_at(r, k) * t.bt[s - 1][k];
+            t.bt[s][r] = (u32)acc;
+        }
+    for (int r = 0; r < 12; r++) {
+        u64 w = 0;
+        for (int c = 0; c < 12; c++) w += A[r][c];
+        for (int i = 2; i <= K; i++) w += t.bt[K - i][r];
+        if (w > t.max_weight) t.max_weight = w;
+    }
+    return t;
+}
+// per-block affine offsets (they depend on the block's round constants): k0[j-1] = Kc_j[0] for j < K, kK = Kc_K
+template <int K> struct BlkConst { u64 k0[K]; u64 kK[12]; };
+template <int K> constexpr BlkConst<K> make_blk(int first_round) {   // the block does rounds first_round .. first_round+K-1
+    BlkConst<K> b{};
+    u64 kc[12] = {}, nx[12] = {};
+    for (int i = 0; i < 12; i++) kc[i] = RC_CE[12 * (first_round + 1) + i];
+    for (int j = 1; j <= K; j++) {
+        if (j > 1) {
+            for (int r = 0; r < 12; r++) {
+                unsigned __int128 acc = RC_CE[12 * (first_round + j) + r];
+                for (int k = 1; k < 12; k++) acc += (unsigned __int128)m_at(r, k) * kc[k];
+                nx[r] = (u64)(acc % PRIME);
+            }
+            for (int r = 0; r < 12; r++) kc[r] = nx[r];
+        }
+        if (j < K) b.k0[j - 1] = kc[0];
+    }
+    b.k0[K - 1] = 0;
+    for (int r = 0; r < 12; r++) b.kK[r] = kc[r];
+    return b;
+}
+}  // namespace pblk
+
+// partial rounds 4..23 as five blocks of 4, 24..25 as one block of 2
+static __device__ const pblk::BlkConst<4> PB4[5] = {pblk::make_blk<4>(4), pblk::make_blk<4>(8), pblk::make_blk<4>(12),
+                                                    pblk::make_blk<4>(16), pblk::make_blk<4>(20)};
+static __device__ const pblk::BlkConst<2> PB2[1] = {pblk::make_blk<2>(24)};
+
+// s: state entering partial round t with that round's constants already added; on return: the state entering
+// round t+K with ITS constants added.  Non-canonical in and out.
+template <int K>
+__device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst<K> &kc) {
+    constexpr pblk::Tab<K> T = pblk::make_tab<K>();
+    // al <= (2^32-1) W + 2^32 and ah <= 2^32 + 2^32 + (2^32-1) W must fit 64 bits, value < 2^96
+    static_assert(T.max_weight + 2 < (1ULL << 32), "unreduced accumulation would overflow");
+    u32 lo[12], hi[12], slo[K], shi[K];
+    u64 sig = sbox7_nc(s[0]);
+    lo[0] = (u32)sig; hi[0] = (u32)(sig >> 32);
+#pragma unroll
+    for (int i = 1; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+#pragma unroll
+    for (int j = 1; j < K; j++) {           // z_j[0] -> sigma_{j+1}
+        u64 al = (u32)kc.k0[j - 1];
+#pragma unroll
+        for (int c = 0; c < 12; c++) al += (u64)lo[c] * T.a0[j - 1][c];
+#pragma unroll
+        for (int i = 2; i <= j; i++) al += (u64)slo[i - 1] * T.bt[j - i][0];
+        u64 ah = (al >> 32) + (kc.k0[j - 1] >> 32);
+#pragma unroll
+        for (int c = 0; c < 12; c++) ah += (u64)hi[c] * T.a0[j - 1][c];
+#pragma unroll
+        for (int i = 2; i <= j; i++) ah += (u64)shi[i - 1] * T.bt[j - i][0];
+        sig = sbox7_nc(fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32)));
+        slo[j] = (u32)sig; shi[j] = (u32)(sig >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {          // z_K
+        u64 al = (u32)kc.kK[r];
+#pragma unroll
+        for (int c = 0; c < 12; c++) al += (u64)lo[c] * T.aK[r][c];
+#pragma unroll
+        for (int i = 2; i <= K; i++) al += (u64)slo[i - 1] * T.bt[K - i][r];
+        u64 ah = (al >> 32) + (kc.kK[r] >> 32);
+#pragma unroll
+        for (int c = 0; c < 12; c++) ah += (u64)hi[c] * T.aK[r][c];
+#pragma unroll
+        for (int i = 2; i <= K; i++) ah += (u64)shi[i - 1] * T.bt[K - i][r];
+        s[r] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
+        if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonical out
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[i]);
@@ -138,11 +262,17 @@ __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonic
         mds_add_nc(s, RC + rc);
         rc += 12;
     }
+#ifdef GLP_POSEIDON_PLAIN_PARTIAL
     for (int r = 0; r < 22; r++) {
         s[0] = sbox7_nc(s[0]);
         mds_add_nc(s, RC + rc);
         rc += 12;
     }
+#else
+    for (int b = 0; b < 5; b++) partial_block_nc<4>(s, PB4[b]);
+    partial_block_nc<2>(s, PB2[0]);
+    rc += 22 * 12;
+#endif
     for (int r = 0; r < 3; r++) {
         sbox_layer_nc(s);
         mds_add_nc(s, RC + rc);

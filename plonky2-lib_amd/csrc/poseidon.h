@@ -253,10 +253,17 @@ __device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst
     }
 }
 
+// profiles/isa_slots.py compiles with -DGLP_POSEIDON_FLAT so that the whole permutation is one basic block it can count
+#ifdef GLP_POSEIDON_FLAT
+#define GLP_POSEIDON_UNROLL _Pragma("unroll")
+#else
+#define GLP_POSEIDON_UNROLL _Pragma("nounroll")
+#endif
 __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonical out
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[i]);
     int rc = 12;
+    GLP_POSEIDON_UNROLL
     for (int r = 0; r < 4; r++) {
         sbox_layer_nc(s);
         mds_add_nc(s, RC + rc);
@@ -269,10 +276,12 @@ __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonic
         rc += 12;
     }
 #else
+    GLP_POSEIDON_UNROLL
     for (int b = 0; b < 5; b++) partial_block_nc<4>(s, PB4[b]);
     partial_block_nc<2>(s, PB2[0]);
     rc += 22 * 12;
 #endif
+    GLP_POSEIDON_UNROLL
     for (int r = 0; r < 3; r++) {
         sbox_layer_nc(s);
         mds_add_nc(s, RC + rc);

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Issue-slot count of one Poseidon permutation, from the gfx950 ISA hipcc emits for csrc/merkle.hip.
 A slot = one full-rate VALU wave-instruction (2 cycles on a SIMD-32); per-opcode weights are calibrated by
-profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 1.75).  The permutation is three loops: 4 full rounds, 22 partial rounds, 4 full rounds; per-loop
-bodies are recognised by their multiply count.  Prints JSON."""
+profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 1.75).  Every basic block of k_permute_states is
+counted and weighted by its trip count (loops: 4 full rounds, 5 four-round partial blocks, 3 full rounds).  Prints JSON."""
 import collections
 import json
 import os
@@ -24,37 +24,49 @@ def main():
     src = os.path.join(ROOT, "plonky2-lib_amd", "csrc", "merkle.hip")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "merkle.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DGLP_LDE_NO_HOIST", "-S", "--cuda-device-only",
                                "-o", out, src], stderr=subprocess.DEVNULL)
         txt = open(out).read()
     body = txt[txt.index("_ZN3glp16k_permute_statesEPmm:"):]
     body = body[:body.index("s_endpgm")]
-    blocks, cur = [], []
+    # basic blocks in program order; a block that branches back to its own label is a loop body
+    blocks, cur, label = [], [], None
     for l in body.split("\n"):
-        if re.match(r"^\.LBB\d+_\d+:", l):
-            blocks.append(cur); cur = []
-        else:
-            m = re.match(r"^\s+([vs]_\w+|ds_\w+|global_\w+)", l)
-            if m:
-                cur.append(m.group(1))
-    blocks.append(cur)
-    res = []
-    for b in blocks:
-        c = collections.Counter(b)
-        mads = c["v_mad_u64_u32"]
-        if mads < 100:
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            blocks.append((label, cur)); cur, label = [], m.group(1)
             continue
+        m = re.match(r"^\s+([vs]_\w+|ds_\w+|global_\w+)(.*)", l)
+        if m:
+            cur.append((m.group(1), m.group(2)))
+            if m.group(1).startswith("s_cbranch") and label is not None and label in m.group(2):
+                blocks.append((label, cur)); cur, label = [], None      # code after a back-branch is straight-line again
+    blocks.append((label, cur))
+    # permute(): 4 full rounds (loop x4), partial rounds 4..23 as 5 blocks of 4 (loop x5), rounds 24..25 as one
+    # block of 2 (straight line), 3 full rounds (loop x3), last full round (straight line)
+    trips = [4, 5, 3]
+    res, total, loops = [], 0.0, 0
+    for lab, b in blocks:
+        ops = [o for o, _ in b]
+        c = collections.Counter(ops)
+        is_loop = lab is not None and any(o.startswith("s_cbranch") and lab in rest for o, rest in b)
+        mads = c["v_mad_u64_u32"]
         valu = sum(v for k, v in c.items() if k.startswith("v_"))
         slots = sum(v * (1.0 if k in FULL else HALF_WEIGHT) for k, v in c.items() if k.startswith("v_"))
-        res.append({"mads": mads, "valu_instructions": valu, "issue_slots": slots, "s_nop": c["s_nop"]})
-    # loop bodies: the partial round has the fewest multiplies; a full-round body has 11 more S-boxes
-    part_mads = min(r["mads"] for r in res)
-    part = [r for r in res if r["mads"] == part_mads]
-    full = [r for r in res if 1.4 * part_mads < r["mads"] < 2.6 * part_mads]
-    per_full = min(r["issue_slots"] for r in full) if full else None
-    per_part = min(r["issue_slots"] for r in part) if part else None
-    out = {"loop_bodies": res, "full_round_slots": per_full, "partial_round_slots": per_part,
-           "slots_per_permutation": (8 * per_full + 22 * per_part) if per_full and per_part else None}
+        if valu == 0:
+            continue
+        trip = 1
+        if is_loop:
+            if loops >= len(trips):
+                raise SystemExit("unexpected loop structure in k_permute_states")
+            trip = trips[loops]; loops += 1
+        total += trip * slots
+        res.append({"label": lab, "loop": is_loop, "trip_count": trip, "mads": mads, "valu_instructions": valu,
+                    "issue_slots": slots, "s_nop": c["s_nop"]})
+    if loops != len(trips):
+        raise SystemExit("expected %d loops in k_permute_states, found %d" % (len(trips), loops))
+    out = {"blocks": res, "mads_per_permutation": sum(r["mads"] * r["trip_count"] for r in res),
+           "slots_per_permutation": total}
     json.dump(out, sys.stdout, indent=1)
     print()
 

@@ -132,40 +132,50 @@ __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
 // ---- partial rounds, K at a time -------------------------------------------------------------------
 // A partial round is x <- M (E x + e0 sbox(x0)) + c  (E zeroes coordinate 0, c = the next round's constants):
 // linear except for ONE S-box, so K of them compose into
-//     z_j = A_j v + sum_{i=2..j} B_{j-i} sigma_i + Kc_j,     v = [sigma_1; x_1..x_11],  sigma_{j+1} = sbox(z_j[0]),
-//     A_1 = M, A_j = M E A_{j-1};  B_0 = M[:,0], B_t = M E B_{t-1};  Kc_1 = c_1, Kc_j = M E Kc_{j-1} + c_j
-// and only z_K is needed in full: rows 0 of A_1..A_{K-1} (24 multiply-adds each) plus ONE 12-row product with
-// A_K instead of K of them.  The entries stay small integers (A_4 < 2^29, row weight < 2^31.8), so the same
+//     z_j = G_j y + sum_{i=1..j} B_{j-i} sigma_i + Kc_j,    sigma_1 = sbox(x0),  sigma_{j+1} = sbox(z_j[0]),
+//     A_1 = M, A_j = M E A_{j-1};  G_j = A_j E (y = the entering state);  B_0 = M[:,0], B_t = M E B_{t-1};
+//     Kc_1 = c_1, Kc_j = M E Kc_{j-1} + c_j
+// and only z_K is needed in full: rows 0 of G_1..G_{K-1} (24 multiply-adds each) plus ONE 12-row product with
+// G_K instead of K of them.  The entries stay small integers (A_4 < 2^29, row weight < 2^31.8), so the same
 // unreduced 32-bit-limb accumulation + single fold as the plain MDS layer applies: 438 v_mad_u64_u32 per 4
 // rounds instead of 1152.  (plonky2's own "fast partial round" form reaches fewer multiplications but with
 // full-width field constants, which on gfx950 costs more issue slots than this: profiles/r01_ubench_variants.txt.)
+// MERGED: the block also swallows the MDS layer of the full round in front of it (y = that round's S-box outputs,
+// x = M y + c_0, G_j = A_j E M, Kc_0 = c_0): one more 24-term row instead of a 12-row layer; K <= 3 there.
 // Same permutation: tests/test_gpu_commit.py checks it against the oracle's naive schedule.
 namespace pblk {
 constexpr u64 PRIME = 0xFFFFFFFF00000001ULL;
 constexpr u32 CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
 constexpr u64 RC_CE[360] = { GLP_POSEIDON_RC_LIST };
 constexpr u64 m_at(int r, int c) { return CIRC[(c - r + 12) % 12] + ((r == 0 && c == 0) ? 8u : 0u); }
-template <int K> struct Tab {
-    u32 a0[K][12] = {};      // a0[j-1] = row 0 of A_j           (j = 1..K-1 used)
-    u32 aK[12][12] = {};     // A_K
-    u32 bt[K][12] = {};      // B_t, t = 0..K-2 used
+template <int K, bool MERGED> struct Tab {
+    u32 g0[K][12] = {};      // g0[j-1] = row 0 of G_j           (j = 1..K-1 used)
+    u32 gK[12][12] = {};     // G_K
+    u32 bt[K][12] = {};      // B_t, t = 0..K-1
     u64 max_weight = 0;      // largest total coefficient weight of one output (overflow bound)
 };
-template <int K> constexpr Tab<K> make_tab() {
-    Tab<K> t{};
-    u64 A[12][12] = {}, N[12][12] = {};
+template <int K, bool MERGED> constexpr Tab<K, MERGED> make_tab() {
+    Tab<K, MERGED> t{};
+    u64 A[12][12] = {}, N[12][12] = {}, G[12][12] = {};
     for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) A[r][c] = m_at(r, c);
-    for (int c = 0; c < 12; c++) t.a0[0][c] = (u32)A[0][c];
-    for (int j = 2; j <= K; j++) {
-        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {
-            u64 acc = 0;
-            for (int k = 1; k < 12; k++) acc += m_at(r, k) * A[k][c];
-            N[r][c] = acc;
+    for (int j = 1; j <= K; j++) {
+        if (j > 1) {
+            for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {
+                u64 acc = 0;
+                for (int k = 1; k < 12; k++) acc += m_at(r, k) * A[k][c];
+                N[r][c] = acc;
+            }
+            for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) A[r][c] = N[r][c];
         }
-        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) A[r][c] = N[r][c];
-        if (j < K) for (int c = 0; c < 12; c++) t.a0[j - 1][c] = (u32)A[0][c];
+        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {       // G_j = A_j E (M)
+            u64 acc = 0;
+            if (MERGED) { for (int k = 1; k < 12; k++) acc += A[r][k] * m_at(k, c); }
+            else acc = c == 0 ? 0 : A[r][c];
+            G[r][c] = acc;
+        }
+        if (j < K) for (int c = 0; c < 12; c++) t.g0[j - 1][c] = (u32)G[0][c];
     }
-    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) t.aK[r][c] = (u32)A[r][c];
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) t.gK[r][c] = (u32)G[r][c];
     for (int r = 0; r < 12; r++) t.bt[0][r] = (u32)m_at(r, 0);
     for (int s = 1; s < K; s++)
         for (int r = 0; r < 12; r++) {
@@ -175,120 +185,139 @@ template <int K> constexpr Tab<K> make_tab() {
         }
     for (int r = 0; r < 12; r++) {
         u64 w = 0;
-        for (int c = 0; c < 12; c++) w += A[r][c];
-        for (int i = 2; i <= K; i++) w += t.bt[K - i][r];
+        for (int c = 0; c < 12; c++) { w += G[r][c]; if (G[r][c] >> 32) w = ~0ULL >> 1; }
+        for (int i = 1; i <= K; i++) w += t.bt[K - i][r];
         if (w > t.max_weight) t.max_weight = w;
     }
     return t;
 }
-// per-block affine offsets (they depend on the block's round constants): k0[j-1] = Kc_j[0] for j < K, kK = Kc_K
-template <int K> struct BlkConst { u64 k0[K]; u64 kK[12]; };
-template <int K> constexpr BlkConst<K> make_blk(int first_round) {   // the block does rounds first_round .. first_round+K-1
+// per-block affine offsets (they depend on the block's round constants): kpre = c_0[0] (MERGED only),
+// k0[j-1] = Kc_j[0] for j < K, kK = Kc_K
+template <int K> struct BlkConst { u64 kpre; u64 k0[K]; u64 kK[12]; };
+// the block does partial rounds first_round .. first_round+K-1; MERGED: plus the linear layer in front of them
+template <int K, bool MERGED> constexpr BlkConst<K> make_blk(int first_round) {
     BlkConst<K> b{};
     u64 kc[12] = {}, nx[12] = {};
-    for (int i = 0; i < 12; i++) kc[i] = RC_CE[12 * (first_round + 1) + i];
-    for (int j = 1; j <= K; j++) {
-        if (j > 1) {
-            for (int r = 0; r < 12; r++) {
-                unsigned __int128 acc = RC_CE[12 * (first_round + j) + r];
-                for (int k = 1; k < 12; k++) acc += (unsigned __int128)m_at(r, k) * kc[k];
-                nx[r] = (u64)(acc % PRIME);
-            }
-            for (int r = 0; r < 12; r++) kc[r] = nx[r];
+    for (int i = 0; i < 12; i++) kc[i] = RC_CE[12 * (first_round + (MERGED ? 0 : 1)) + i];
+    b.kpre = MERGED ? kc[0] : 0;
+    for (int j = MERGED ? 1 : 2; j <= K; j++) {
+        for (int r = 0; r < 12; r++) {
+            unsigned __int128 acc = RC_CE[12 * (first_round + j) + r];
+            for (int k = 1; k < 12; k++) acc += (unsigned __int128)m_at(r, k) * kc[k];
+            nx[r] = (u64)(acc % PRIME);
         }
+        for (int r = 0; r < 12; r++) kc[r] = nx[r];
         if (j < K) b.k0[j - 1] = kc[0];
     }
+    if (!MERGED && K > 1) b.k0[0] = RC_CE[12 * (first_round + 1)];
     b.k0[K - 1] = 0;
     for (int r = 0; r < 12; r++) b.kK[r] = kc[r];
     return b;
 }
 }  // namespace pblk
 
-// partial rounds 4..23 as five blocks of 4, 24..25 as one block of 2
-static __device__ const pblk::BlkConst<4> PB4[5] = {pblk::make_blk<4>(4), pblk::make_blk<4>(8), pblk::make_blk<4>(12),
-                                                    pblk::make_blk<4>(16), pblk::make_blk<4>(20)};
-static __device__ const pblk::BlkConst<2> PB2[1] = {pblk::make_blk<2>(24)};
+// rounds 3(linear layer)+4..6 merged, 7..22 as four blocks of 4, 23..25 as one block of 3
+static __device__ const pblk::BlkConst<3> PBM[1] = {pblk::make_blk<3, true>(4)};
+static __device__ const pblk::BlkConst<4> PB4[4] = {pblk::make_blk<4, false>(7), pblk::make_blk<4, false>(11),
+                                                    pblk::make_blk<4, false>(15), pblk::make_blk<4, false>(19)};
+static __device__ const pblk::BlkConst<3> PB3[1] = {pblk::make_blk<3, false>(23)};
 
-// s: state entering partial round t with that round's constants already added; on return: the state entering
-// round t+K with ITS constants added.  Non-canonical in and out.
-template <int K>
+// unreduced row: sum_c y_c * g[c] + sum_{i<ns} sigma_i * bcoef(i) + k, folded to a non-canonical u64
+#define GLP_PB_ROW(OUT, GROW, KCONST, NS, BCOEF)                                                    \
+    do {                                                                                            \
+        const u64 _k = (KCONST);                                                                    \
+        u64 al = (u32)_k;                                                                           \
+        _Pragma("unroll") for (int c = 0; c < 12; c++) if ((GROW)[c] != 0) al += (u64)lo[c] * (GROW)[c];   \
+        _Pragma("unroll") for (int i = 0; i < (NS); i++) al += (u64)slo[i] * (BCOEF);               \
+        u64 ah = (al >> 32) + (_k >> 32);                                                           \
+        _Pragma("unroll") for (int c = 0; c < 12; c++) if ((GROW)[c] != 0) ah += (u64)hi[c] * (GROW)[c];   \
+        _Pragma("unroll") for (int i = 0; i < (NS); i++) ah += (u64)shi[i] * (BCOEF);               \
+        (OUT) = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));                                   \
+    } while (0)
+
+// !MERGED: s = state entering partial round t with that round's constants already added.  MERGED: s = S-box outputs
+// of the full round before partial round t.  On return: the state entering round t+K with ITS constants added.
+// Non-canonical in and out.
+template <int K, bool MERGED>
 __device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst<K> &kc) {
-    constexpr pblk::Tab<K> T = pblk::make_tab<K>();
+    constexpr pblk::Tab<K, MERGED> T = pblk::make_tab<K, MERGED>();
     // al <= (2^32-1) W + 2^32 and ah <= 2^32 + 2^32 + (2^32-1) W must fit 64 bits, value < 2^96
     static_assert(T.max_weight + 2 < (1ULL << 32), "unreduced accumulation would overflow");
     u32 lo[12], hi[12], slo[K], shi[K];
-    u64 sig = sbox7_nc(s[0]);
-    lo[0] = (u32)sig; hi[0] = (u32)(sig >> 32);
 #pragma unroll
-    for (int i = 1; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    u64 x0 = s[0];
+    if constexpr (MERGED) {
+        constexpr u32 MROW0[12] = {25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};   // M[0,:]
+        GLP_PB_ROW(x0, MROW0, kc.kpre, 0, 0u);
+    }
+    u64 sig = sbox7_nc(x0);
+    slo[0] = (u32)sig; shi[0] = (u32)(sig >> 32);
 #pragma unroll
     for (int j = 1; j < K; j++) {           // z_j[0] -> sigma_{j+1}
-        u64 al = (u32)kc.k0[j - 1];
-#pragma unroll
-        for (int c = 0; c < 12; c++) al += (u64)lo[c] * T.a0[j - 1][c];
-#pragma unroll
-        for (int i = 2; i <= j; i++) al += (u64)slo[i - 1] * T.bt[j - i][0];
-        u64 ah = (al >> 32) + (kc.k0[j - 1] >> 32);
-#pragma unroll
-        for (int c = 0; c < 12; c++) ah += (u64)hi[c] * T.a0[j - 1][c];
-#pragma unroll
-        for (int i = 2; i <= j; i++) ah += (u64)shi[i - 1] * T.bt[j - i][0];
-        sig = sbox7_nc(fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32)));
+        u64 z;
+        GLP_PB_ROW(z, T.g0[j - 1], kc.k0[j - 1], j, T.bt[j - 1 - i][0]);
+        sig = sbox7_nc(z);
         slo[j] = (u32)sig; shi[j] = (u32)(sig >> 32);
     }
 #pragma unroll
     for (int r = 0; r < 12; r++) {          // z_K
-        u64 al = (u32)kc.kK[r];
-#pragma unroll
-        for (int c = 0; c < 12; c++) al += (u64)lo[c] * T.aK[r][c];
-#pragma unroll
-        for (int i = 2; i <= K; i++) al += (u64)slo[i - 1] * T.bt[K - i][r];
-        u64 ah = (al >> 32) + (kc.kK[r] >> 32);
-#pragma unroll
-        for (int c = 0; c < 12; c++) ah += (u64)hi[c] * T.aK[r][c];
-#pragma unroll
-        for (int i = 2; i <= K; i++) ah += (u64)shi[i - 1] * T.bt[K - i][r];
-        s[r] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
+        GLP_PB_ROW(s[r], T.gK[r], kc.kK[r], K, T.bt[K - 1 - i][r]);
         if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// profiles/isa_slots.py compiles with -DGLP_POSEIDON_FLAT so that the whole permutation is one basic block it can count
-#ifdef GLP_POSEIDON_FLAT
-#define GLP_POSEIDON_UNROLL _Pragma("unroll")
-#else
-#define GLP_POSEIDON_UNROLL _Pragma("nounroll")
-#endif
+// constants added by the full rounds' linear layers (= the NEXT round's constants): rounds 0..2 add those of rounds
+// 1..3, rounds 26..28 those of 27..29, round 29 adds none; round 3's linear layer is inside the merged block
+struct FullNext { u64 k[8][12]; };
+constexpr FullNext make_full_next() {
+    FullNext f{};
+    for (int r = 0; r < 3; r++) for (int i = 0; i < 12; i++) { f.k[r][i] = pblk::RC_CE[12 * (r + 1) + i]; f.k[4 + r][i] = pblk::RC_CE[12 * (27 + r) + i]; }
+    return f;
+}
+static __device__ const FullNext RCN = make_full_next();
+
+// One copy of the S-box layer and of the MDS layer serves both halves (the two full-round phases are the same loop):
+// the whole permutation is ~30 KB of code instead of ~62 KB, inside the 64 KB instruction cache a CU pair shares.
 __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonical out
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[i]);
-    int rc = 12;
-    GLP_POSEIDON_UNROLL
-    for (int r = 0; r < 4; r++) {
-        sbox_layer_nc(s);
-        mds_add_nc(s, RC + rc);
-        rc += 12;
-    }
 #ifdef GLP_POSEIDON_PLAIN_PARTIAL
-    for (int r = 0; r < 22; r++) {
-        s[0] = sbox7_nc(s[0]);
-        mds_add_nc(s, RC + rc);
-        rc += 12;
-    }
-#else
-    GLP_POSEIDON_UNROLL
-    for (int b = 0; b < 5; b++) partial_block_nc<4>(s, PB4[b]);
-    partial_block_nc<2>(s, PB2[0]);
-    rc += 22 * 12;
-#endif
-    GLP_POSEIDON_UNROLL
-    for (int r = 0; r < 3; r++) {
-        sbox_layer_nc(s);
-        mds_add_nc(s, RC + rc);
-        rc += 12;
-    }
+    int rc = 12;
+    for (int r = 0; r < 4; r++) { sbox_layer_nc(s); mds_add_nc(s, RC + rc); rc += 12; }
+    for (int r = 0; r < 22; r++) { s[0] = sbox7_nc(s[0]); mds_add_nc(s, RC + rc); rc += 12; }
+    for (int r = 0; r < 3; r++) { sbox_layer_nc(s); mds_add_nc(s, RC + rc); rc += 12; }
     sbox_layer_nc(s);
     mds_add_nc(s, RC_ZERO);
+#else
+#ifdef GLP_POSEIDON_FLAT       // counting build for profiles/isa_slots.py: the same rounds with no loop at all
+#define GLP_FULL_ROUND(i) sbox_layer_nc(s); mds_add_nc(s, RCN.k[i]);
+    GLP_FULL_ROUND(0) GLP_FULL_ROUND(1) GLP_FULL_ROUND(2)
+    sbox_layer_nc(s);
+    partial_block_nc<3, true>(s, PBM[0]);
+    partial_block_nc<4, false>(s, PB4[0]); partial_block_nc<4, false>(s, PB4[1]);
+    partial_block_nc<4, false>(s, PB4[2]); partial_block_nc<4, false>(s, PB4[3]);
+    partial_block_nc<3, false>(s, PB3[0]);
+    GLP_FULL_ROUND(4) GLP_FULL_ROUND(5) GLP_FULL_ROUND(6) GLP_FULL_ROUND(7)
+#undef GLP_FULL_ROUND
+#else
+#pragma nounroll
+    for (int half = 0; half < 2; half++) {
+#pragma nounroll
+        for (int r = 0; r < 4; r++) {
+            sbox_layer_nc(s);
+            if (half == 0 && r == 3) break;                 // round 3's linear layer is part of the merged block
+            mds_add_nc(s, RCN.k[4 * half + r]);
+        }
+        if (half == 0) {
+            partial_block_nc<3, true>(s, PBM[0]);           // linear layer of round 3 + rounds 4..6
+#pragma nounroll
+            for (int b = 0; b < 4; b++) partial_block_nc<4, false>(s, PB4[b]);    // rounds 7..22
+            partial_block_nc<3, false>(s, PB3[0]);          // rounds 23..25
+        }
+    }
+#endif
+#endif
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
 }

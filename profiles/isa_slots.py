@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Issue-slot count of one Poseidon permutation, from the gfx950 ISA hipcc emits for csrc/merkle.hip.
 A slot = one full-rate VALU wave-instruction (2 cycles on a SIMD-32); per-opcode weights are calibrated by
-profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 1.75).  Every basic block of k_permute_states is
-counted and weighted by its trip count (loops: 4 full rounds, 5 four-round partial blocks, 3 full rounds).  Prints JSON."""
+profiles/r01_ubench_opcode_rates.txt (full-rate set below counts 1, everything else 1.75).  The kernel is compiled with every round
+loop unrolled (-DGLP_POSEIDON_FLAT), so the static count of k_permute_states is the dynamic count.  Prints JSON."""
 import collections
 import json
 import os
@@ -24,49 +24,32 @@ def main():
     src = os.path.join(ROOT, "plonky2-lib_amd", "csrc", "merkle.hip")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "merkle.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DGLP_LDE_NO_HOIST", "-S", "--cuda-device-only",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DGLP_LDE_NO_HOIST", "-DGLP_POSEIDON_FLAT", "-S", "--cuda-device-only",
                                "-o", out, src], stderr=subprocess.DEVNULL)
         txt = open(out).read()
     body = txt[txt.index("_ZN3glp16k_permute_statesEPmm:"):]
     body = body[:body.index("s_endpgm")]
-    # basic blocks in program order; a block that branches back to its own label is a loop body
-    blocks, cur, label = [], [], None
+    # compiled with -DGLP_POSEIDON_FLAT every round loop is unrolled: the kernel is straight-line code (the bounds
+    # check branches forward only), so the static instruction count IS the dynamic count of one permutation
+    ops = []
+    labels = set()
     for l in body.split("\n"):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
-            blocks.append((label, cur)); cur, label = [], m.group(1)
+            labels.add(m.group(1))
             continue
         m = re.match(r"^\s+([vs]_\w+|ds_\w+|global_\w+)(.*)", l)
         if m:
-            cur.append((m.group(1), m.group(2)))
-            if m.group(1).startswith("s_cbranch") and label is not None and label in m.group(2):
-                blocks.append((label, cur)); cur, label = [], None      # code after a back-branch is straight-line again
-    blocks.append((label, cur))
-    # permute(): 4 full rounds (loop x4), partial rounds 4..23 as 5 blocks of 4 (loop x5), rounds 24..25 as one
-    # block of 2 (straight line), 3 full rounds (loop x3), last full round (straight line)
-    trips = [4, 5, 3]
-    res, total, loops = [], 0.0, 0
-    for lab, b in blocks:
-        ops = [o for o, _ in b]
-        c = collections.Counter(ops)
-        is_loop = lab is not None and any(o.startswith("s_cbranch") and lab in rest for o, rest in b)
-        mads = c["v_mad_u64_u32"]
-        valu = sum(v for k, v in c.items() if k.startswith("v_"))
-        slots = sum(v * (1.0 if k in FULL else HALF_WEIGHT) for k, v in c.items() if k.startswith("v_"))
-        if valu == 0:
-            continue
-        trip = 1
-        if is_loop:
-            if loops >= len(trips):
-                raise SystemExit("unexpected loop structure in k_permute_states")
-            trip = trips[loops]; loops += 1
-        total += trip * slots
-        res.append({"label": lab, "loop": is_loop, "trip_count": trip, "mads": mads, "valu_instructions": valu,
-                    "issue_slots": slots, "s_nop": c["s_nop"]})
-    if loops != len(trips):
-        raise SystemExit("expected %d loops in k_permute_states, found %d" % (len(trips), loops))
-    out = {"blocks": res, "mads_per_permutation": sum(r["mads"] * r["trip_count"] for r in res),
-           "slots_per_permutation": total}
+            if m.group(1).startswith("s_cbranch") and any(lab in m.group(2) for lab in labels):
+                raise SystemExit("backward branch in the flat build: loops were not fully unrolled")
+            ops.append(m.group(1))
+    c = collections.Counter(ops)
+    valu = sum(v for k, v in c.items() if k.startswith("v_"))
+    slots = sum(v * (1.0 if k in FULL else HALF_WEIGHT) for k, v in c.items() if k.startswith("v_"))
+    out = {"build": "-DGLP_POSEIDON_FLAT (all round loops unrolled; the shipped build keeps them rolled: same instructions per round)",
+           "mads_per_permutation": c["v_mad_u64_u32"], "valu_instructions": valu, "s_nop": c["s_nop"],
+           "full_rate_instructions": sum(v for k, v in c.items() if k in FULL),
+           "slots_per_permutation": slots, "top_opcodes": dict(c.most_common(14))}
     json.dump(out, sys.stdout, indent=1)
     print()
 

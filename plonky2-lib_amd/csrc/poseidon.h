@@ -109,18 +109,21 @@ __device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
     u32 lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    // 16 and 2 held in SGPRs the compiler cannot see through: otherwise it turns those terms into
+    // v_lshl_add_u64 on a (limb, 0) register pair it has to build with two moves (3.75 issue slots against 1.75)
+    u32 c16 = 16, c2 = 2;
+    asm volatile("" : "+s"(c16), "+s"(c2));
 #pragma unroll
     for (int r = 0; r < 12; r++) {
         // low halves first; the high-half chain then starts from the low chain's overflow, so the 96-bit row value
         // (ah : low 32 bits of al) needs no carry combine
-        u64 al = (u32)rc[r];
+        u64 al = (u64)(u32)rc[r] + (u64)lo[r] * (r == 0 ? C[0] + 8 : C[0]);
+        asm("" : "+v"(al));            // keep the constant as the first multiply-add's addend (no separate 64-bit add)
 #pragma unroll
-        for (int i = 0; i < 12; i++) al += (u64)lo[(i + r) % 12] * C[i];
-        if (r == 0) al += (u64)lo[0] * 8;
+        for (int i = 1; i < 12; i++) al += (u64)lo[(i + r) % 12] * (C[i] == 16 ? c16 : C[i] == 2 ? c2 : C[i]);
         u64 ah = (al >> 32) + (rc[r] >> 32);
 #pragma unroll
-        for (int i = 0; i < 12; i++) ah += (u64)hi[(i + r) % 12] * C[i];
-        if (r == 0) ah += (u64)hi[0] * 8;
+        for (int i = 0; i < 12; i++) ah += (u64)hi[(i + r) % 12] * (i == 0 && r == 0 ? C[0] + 8 : C[i] == 16 ? c16 : C[i] == 2 ? c2 : C[i]);
 #ifdef GLP_MDS_FOLD_C
         s[r] = fold96_c((ah << 32) | (u32)al, (u32)(ah >> 32));
 #else

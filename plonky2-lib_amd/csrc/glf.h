@@ -190,6 +190,17 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
     return fold96_nc((u64)y, (u32)(y >> 64));
 #endif
 }
+// a canonical (< p), b ANY u64 -> a + b as a non-canonical u64.  A wrapped sum is < p - 1, so adding 2^64 mod p back
+// cannot wrap again.
+__device__ __forceinline__ u64 add_cnc(u64 a, u64 b) {
+    u32 c, c2;
+    u32 lo = __builtin_addc((u32)a, (u32)b, 0u, &c);
+    u32 hi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c, &c);
+    const u32 m = 0u - c;
+    lo = __builtin_addc(lo, m, 0u, &c2);
+    hi = __builtin_addc(hi, 0u, c2, &c2);
+    return ((u64)hi << 32) | lo;
+}
 // canonical product through the limb form
 __device__ __forceinline__ u64 mul_c(u64 a, u64 b) { return canon(mul_nc(a, b)); }
 // x * 2^E mod p for a compile-time 0 < E < 96 (x any u64) -> canonical.  Every 64th root of unity of

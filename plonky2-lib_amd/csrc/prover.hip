@@ -214,14 +214,29 @@ __global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 l
     }
 }
 
-__device__ __forceinline__ u64 range_product(u64 v, u32 bound) {   // prod_{x < bound} (v - x)
+// prod_{x < bound} (v - x), v canonical -> NON-canonical u64 (it only ever feeds acc_fma, which takes any u64)
+__device__ __forceinline__ u64 range_product(u64 v, u32 bound) {
     if (bound == 4) {                       // v(v-3) * (v-1)(v-2) = u (u + 2): two multiplications instead of three
         const u64 u = mul(v, sub(v, 3));
-        return mul(u, add(u, 2));
+        return mul_nc(u, add_cnc(2, u));
     }
     u64 p = v;
-    for (u32 x = 1; x < bound; x++) p = mul(p, sub(v, (u64)x));
-    return p;
+    for (u32 x = 1; x + 1 < bound; x++) p = mul(p, sub(v, (u64)x));
+    return bound > 1 ? mul_nc(p, sub(v, (u64)(bound - 1))) : p;
+}
+// sum_j 4^j limb_j over up to 16 canonical limbs without a modular operation per limb: the 32-bit halves are
+// accumulated separately (each sum < 2^32 (4^16 - 1) / 3 < 2^64 / 3) and folded once.
+struct Base4Sum { u64 lo, hi; };
+__device__ __forceinline__ void b4_zero(Base4Sum &b) { b.lo = 0; b.hi = 0; }
+__device__ __forceinline__ void b4_add(Base4Sum &b, u64 limb, u32 j /* < 16 */) {
+    const u32 w = 1u << (2 * j);
+    b.lo += (u64)(u32)limb * w;
+    b.hi += (u64)(u32)(limb >> 32) * w;
+}
+__device__ __forceinline__ u64 b4_value(const Base4Sum &b) {       // canonical
+    const u64 l = b.lo + (b.hi << 32);
+    const u32 h = (u32)(b.hi >> 32) + (l < b.lo ? 1u : 0u);
+    return canon(fold96_nc(l, h));
 }
 // Unreduced accumulator for sum_k c_k * alpha^k: 128-bit products are added into five 32-bit words and folded
 // once per gate instead of once per constraint (a modular multiply-add costs ~40 issue slots, this ~19).
@@ -280,14 +295,20 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
 // Base-4 limb columns LIMBS[j*N], j = COUNT-1 .. 0: eight loads are issued before their values are used (the gate
 // loops have run-time bounds, so the compiler cannot software-pipeline them itself).  Constraint index KIDX may use _j.
 #define LIMBS4_DESC(LIMBS, COUNT, SPLIT, KIDX, ACCLO, ACCHI)                                                      \
-    for (int _j0 = (int)(COUNT); _j0 > 0; _j0 -= 8) {                                                             \
-        u64 _lv[8];                                                                                                \
-        _Pragma("unroll") for (int _t = 0; _t < 8; _t++) if (_t < _j0) _lv[_t] = (LIMBS)[(size_t)(_j0 - 1 - _t) * N]; \
-        _Pragma("unroll") for (int _t = 0; _t < 8; _t++) if (_t < _j0) {                                          \
-            const int _j = _j0 - 1 - _t;                                                                          \
-            EMIT((KIDX), range_product(_lv[_t], 4));                                                               \
-            if (_j < (int)(SPLIT)) ACCLO = add(dbl(dbl(ACCLO)), _lv[_t]); else ACCHI = add(dbl(dbl(ACCHI)), _lv[_t]); \
+    {                                                                                                             \
+        Base4Sum _slo, _shi;                                                                                      \
+        b4_zero(_slo); b4_zero(_shi);                                                                             \
+        for (int _j0 = (int)(COUNT); _j0 > 0; _j0 -= 8) {                                                         \
+            u64 _lv[8];                                                                                            \
+            _Pragma("unroll") for (int _t = 0; _t < 8; _t++) if (_t < _j0) _lv[_t] = (LIMBS)[(size_t)(_j0 - 1 - _t) * N]; \
+            _Pragma("unroll") for (int _t = 0; _t < 8; _t++) if (_t < _j0) {                                      \
+                const int _j = _j0 - 1 - _t;                                                                      \
+                EMIT((KIDX), range_product(_lv[_t], 4));                                                           \
+                if (_j < (int)(SPLIT)) b4_add(_slo, _lv[_t], (u32)_j); else b4_add(_shi, _lv[_t], (u32)(_j - (int)(SPLIT))); \
+            }                                                                                                     \
         }                                                                                                         \
+        ACCLO = b4_value(_slo);                                                                                   \
+        if ((int)(COUNT) > (int)(SPLIT)) ACCHI = b4_value(_shi);                                                  \
     }
         switch (TYPE >= 0 ? (u32)TYPE : g.type) {   // TYPE >= 0: the switch folds to one case at compile time
         case GLP_GATE_CONSTANT:
@@ -568,10 +589,13 @@ __global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; t++)
                 if (jb + t < j1) {
-                    const u64 kx = mul(a.k_is[jb + t], x);
+                    // lazy chain: the running products and the beta terms stay non-canonical u64 (mul_nc takes any
+                    // u64); only w + gamma is a canonical addition, shared by numerator and denominator
+                    const u64 kx = mul_nc(a.k_is[jb + t], x);
                     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-                        num[c] = mul(num[c], add(add(w8[t], mul(a.betas[c], kx)), a.gammas[c]));
-                        den[c] = mul(den[c], add(add(w8[t], mul(a.betas[c], s8[t])), a.gammas[c]));
+                        const u64 wg = add(w8[t], a.gammas[c]);
+                        num[c] = mul_nc(num[c], add_cnc(wg, mul_nc(a.betas[c], kx)));
+                        den[c] = mul_nc(den[c], add_cnc(wg, mul_nc(a.betas[c], s8[t])));
                     }
                 }
         }

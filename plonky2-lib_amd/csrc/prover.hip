@@ -260,6 +260,39 @@ __device__ __forceinline__ u64 acc_reduce(const Acc160 &a) {      // canonical
     return canon(fold128_nc(a.w0, a.w1, (u32)h, (u32)(h >> 32)));
 }
 
+// Gate constraints: sum_k v_k alpha^k with NO carries per term.  v is cut into 22-bit limbs and alpha^k into 32-bit
+// halves; each of the six limb products (< 2^54) is accumulated in its own 64-bit register by one v_mad_u64_u32, so up
+// to 1024 terms fit before anything can overflow (glp_circuit_create rejects gates with more constraints).  6 issue
+// slots per term against 14 for the 160-bit carry chain above; the limbs of v are shared by all challenges.
+constexpr u32 ACC_MAX_TERMS = 1024;
+struct AccLimb { u64 a00, a01, a10, a11, a20, a21; };     // a[i][j]: limb i of v (bits 22 i ..) times half j of m
+__device__ __forceinline__ void acc2_zero(AccLimb &a) { a.a00 = a.a01 = a.a10 = a.a11 = a.a20 = a.a21 = 0; }
+__device__ __forceinline__ void acc2_fma(AccLimb &a, u32 v0, u32 v1, u32 v2, u64 m) {
+    const u32 m0 = (u32)m, m1 = (u32)(m >> 32);
+    a.a00 += (u64)v0 * m0; a.a01 += (u64)v0 * m1;
+    a.a10 += (u64)v1 * m0; a.a11 += (u64)v1 * m1;
+    a.a20 += (u64)v2 * m0; a.a21 += (u64)v2 * m1;
+}
+template <int E> __device__ __forceinline__ void acc_add_shifted(Acc160 &w, u64 x) {   // w += x << E
+    constexpr int idx = E / 32, sh = E % 32;
+    const u64 lo = x << sh;
+    const u32 t0 = (u32)lo, t1 = (u32)(lo >> 32), t2 = sh ? (u32)(x >> (64 - sh)) : 0u;
+    u32 *W[5] = {&w.w0, &w.w1, &w.w2, &w.w3, &w.w4};
+    u32 c;
+    *W[idx] = __builtin_addc(*W[idx], t0, 0u, &c);
+    *W[idx + 1] = __builtin_addc(*W[idx + 1], t1, c, &c);
+    *W[idx + 2] = __builtin_addc(*W[idx + 2], t2, c, &c);
+    if constexpr (idx + 3 < 5) *W[idx + 3] = __builtin_addc(*W[idx + 3], 0u, c, &c);
+    if constexpr (idx + 4 < 5) *W[idx + 4] = __builtin_addc(*W[idx + 4], 0u, c, &c);
+}
+__device__ __forceinline__ u64 acc2_reduce(const AccLimb &a) {    // canonical
+    Acc160 w;
+    acc_zero(w);
+    acc_add_shifted<0>(w, a.a00); acc_add_shifted<22>(w, a.a10); acc_add_shifted<32>(w, a.a01);
+    acc_add_shifted<44>(w, a.a20); acc_add_shifted<54>(w, a.a11); acc_add_shifted<76>(w, a.a21);
+    return acc_reduce(w);
+}
+
 struct QArgs {
     const u64 *cs, *wl, *zl;        // coset-major LDEs [ncols][R][n]
     u64 *out;                       // [nch][Rq][n]
@@ -284,13 +317,14 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
         for (u32 i = g.group_start; i < g.group_end; i++)
             if (i != g.row) filter = mul(filter, sub((u64)i, s));
         if (a.many_selectors) filter = mul(filter, sub(0xFFFFFFFFull, s));
-        Acc160 ga[MAXCH];
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc_zero(ga[c]);
+        AccLimb ga[MAXCH];
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[c]);
         const u64 *ap = a.apow + k0;
 #define EMIT(k, v)                                                                     \
     do {                                                                               \
         const u64 _v = (v);                                                            \
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(ga[c2], _v, ap[c2 * nt + (k)]);       \
+        const u32 _v0 = (u32)_v & 0x3FFFFFu, _v1 = (u32)(_v >> 22) & 0x3FFFFFu, _v2 = (u32)(_v >> 44);   \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(ga[c2], _v0, _v1, _v2, ap[c2 * nt + (k)]);   \
     } while (0)
 // Base-4 limb columns LIMBS[j*N], j = COUNT-1 .. 0: eight loads are issued before their values are used (the gate
 // loops have run-time bounds, so the compiler cannot software-pipeline them itself).  Constraint index KIDX may use _j.
@@ -554,7 +588,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
         }
 #undef LIMBS4_DESC
 #undef EMIT
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc_reduce(ga[c])));
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[c])));
     }
 }
 
@@ -1343,6 +1377,8 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         default: break;
         }
         GLP_REQUIRE(g.selector_index < d.num_selectors && g.group_start <= g.row && g.row < g.group_end, "bad selector data for gate %u", i);
+        GLP_REQUIRE(g.num_constraints <= ACC_MAX_TERMS, "gate %u: %u constraints exceed the %u the quotient accumulators hold", i,
+                    g.num_constraints, ACC_MAX_TERMS);
         maxc = std::max(maxc, g.num_constraints);
     }
     GLP_REQUIRE(maxc <= d.num_gate_constraints, "num_gate_constraints smaller than a gate's constraint count");

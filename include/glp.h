@@ -194,6 +194,52 @@ GLP_API int glp_prove(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *
 GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *dev_wires,
                              const uint64_t *public_inputs, uint64_t *proof_out);
 
+/* ---- the same proof, stepped by the caller's own transcript -------------------------------------------------
+ * `prove_with_partition_witness` is Fiat-Shamir glue around six device stages.  A Rust integration that keeps
+ * plonky2's own `Challenger` (so that the transcript is the fork's by construction) calls the stages one by one:
+ * each call returns exactly what the Rust prover observes next, and takes exactly the challenges it draws next
+ * [UPSTREAM plonky2 plonk/prover.rs: `challenger.observe_cap(..)` / `get_n_challenges` / `get_extension_challenge`;
+ *  fri/prover.rs: `fri_committed_trees`, `fri_proof_of_work`, `fri_prover_query_rounds`; reached from
+ *  REF src/ecdsa/gadgets/ecdsa.rs:349].  Order (enforced; GLP_ERR_ARG otherwise):
+ *
+ *   glp_session_begin              wires -> iNTT, LDE, Merkle           out: wires cap, hash of the public inputs
+ *   glp_session_partial_products   in: betas, gammas [num_challenges]   out: plonk_zs_partial_products cap
+ *   glp_session_quotient           in: alphas [num_challenges]          out: quotient_polys cap
+ *   glp_session_open               in: zeta (ext)                       out: OpeningSet, 2 words per opening, proof order
+ *   glp_session_fri_combine        in: FRI alpha (ext)
+ *   num_reductions x { glp_session_fri_commit (out: layer cap) ; glp_session_fri_fold (in: beta, ext) }
+ *   glp_session_fri_final_poly     out: final polynomial coefficients (ext)
+ *   glp_pow_search                 (stateless) in: the challenger's sponge state + pending inputs   out: witness
+ *   glp_session_queries            in: pow witness, query indices x_index in [0, 2^(degree_bits+rate_bits))
+ *   glp_session_proof              out: the assembled proof words (same layout as glp_prove)
+ *   glp_session_end
+ *
+ * glp_prove() is this sequence driven by the library's built-in transcript; tests/test_gpu_prove.py drives it with the
+ * oracle's Challenger and requires the identical proof. */
+typedef struct glp_session glp_session;
+/* wires: [num_wires][n]; wires_on_device != 0: an HBM pointer that must stay valid until glp_session_end */
+GLP_API int glp_session_begin(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *wires, int wires_on_device,
+                              const uint64_t *public_inputs, glp_session **out, uint64_t *wires_cap_out /* [2^cap_height][4] */,
+                              uint64_t public_inputs_hash_out[4]);
+GLP_API int glp_session_partial_products(glp_session *s, const uint64_t *betas, const uint64_t *gammas, uint64_t *zs_cap_out);
+GLP_API int glp_session_quotient(glp_session *s, const uint64_t *alphas, uint64_t *quotient_cap_out);
+/* openings_out: 2 * glp_num_openings(circuit) words: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next,
+ * partial_products, quotient_polys (the order `OpeningSet::to_fri_openings` / the proof uses) */
+GLP_API size_t glp_num_openings(const glp_circuit *circuit);
+GLP_API int glp_session_open(glp_session *s, const uint64_t zeta[2], uint64_t *openings_out);
+GLP_API int glp_session_fri_combine(glp_session *s, const uint64_t alpha[2]);
+GLP_API int glp_session_fri_commit(glp_session *s, uint64_t *cap_out);
+GLP_API int glp_session_fri_fold(glp_session *s, const uint64_t beta[2]);
+GLP_API size_t glp_final_poly_len(const glp_circuit *circuit);          /* ext coefficients */
+GLP_API int glp_session_fri_final_poly(glp_session *s, uint64_t *coeffs_out /* [2 * glp_final_poly_len] */);
+/* smallest w such that a duplex sponge in `sponge_state` with `num_pending` (< 8) buffered inputs, after also
+ * observing w, squeezes an element with `bits` leading zero bits (fri_proof_of_work) */
+GLP_API int glp_pow_search(glp_ctx *ctx, const uint64_t sponge_state[12], const uint64_t *pending_inputs, uint32_t num_pending,
+                           uint32_t bits, uint64_t *witness_out);
+GLP_API int glp_session_queries(glp_session *s, uint64_t pow_witness, const uint64_t *indices, uint32_t num_indices);
+GLP_API int glp_session_proof(glp_session *s, uint64_t *proof_out /* glp_proof_words(circuit) */);
+GLP_API void glp_session_end(glp_session *s);
+
 /* plonky2 `ProofWithPublicInputs::to_bytes()` (util/serialization.rs `Buffer::write_proof_with_public_inputs`):
  * every field element as 8 little-endian bytes in the word order above, plus the one-byte sibling
  * count that `write_merkle_proof` puts in front of every Merkle path.  This is the wire format the

@@ -112,12 +112,28 @@ def load_library():
         "glp_proof_to_bytes": [vp, vp, vp, sz],
         "glp_proof_from_bytes": [vp, vp, sz, vp],
         "glp_prove_device": [vp, vp, vp, vp, vp],
+        "glp_session_begin": [vp, vp, vp, C.c_int, vp, C.POINTER(vp), vp, vp],
+        "glp_session_partial_products": [vp, vp, vp, vp],
+        "glp_session_quotient": [vp, vp, vp],
+        "glp_session_open": [vp, vp, vp],
+        "glp_session_fri_combine": [vp, vp],
+        "glp_session_fri_commit": [vp, vp],
+        "glp_session_fri_fold": [vp, vp],
+        "glp_session_fri_final_poly": [vp, vp],
+        "glp_pow_search": [vp, vp, vp, C.c_uint32, C.c_uint32, vp],
+        "glp_session_queries": [vp, C.c_uint64, vp, C.c_uint32],
+        "glp_session_proof": [vp, vp],
+        "glp_session_end": [vp],
     })
+    for name in ("glp_num_openings", "glp_final_poly_len"):
+        getattr(L, name).restype = sz
+        getattr(L, name).argtypes = [vp]
     for name, argtypes in sigs.items():
         getattr(L, name).argtypes = argtypes
     L.glp_ctx_destroy.restype = None
     L.glp_batch_free.restype = None
     L.glp_circuit_free.restype = None
+    L.glp_session_end.restype = None
     _lib = L
     return L
 
@@ -383,3 +399,86 @@ class Circuit:
         _chk(load_library().glp_prove_device(self.ctx._h, self._h, C.c_void_p(dev_wires_ptr), _p(pi) if pi.size else None,
                                              _p(proof)))
         return proof
+
+
+class Session:
+    """One proof stepped by the caller's transcript (include/glp.h, glp_session_*): every method returns what the
+    Rust prover's `Challenger` observes next and takes the challenges it draws next
+    [UPSTREAM plonky2 plonk/prover.rs `prove_with_partition_witness`; reached from REF src/ecdsa/gadgets/ecdsa.rs:349]."""
+
+    def __init__(self, circuit, wires=None, public_inputs=None, dev_wires_ptr=None):
+        L = load_library()
+        self.circuit, d = circuit, circuit.desc
+        self._capn = 1 << d.cap_height
+        pi = _a(d.public_inputs if public_inputs is None else public_inputs)
+        self._h = C.c_void_p()
+        self.wires_cap = np.empty((self._capn, 4), np.uint64)
+        self.public_inputs_hash = np.empty(4, np.uint64)
+        if dev_wires_ptr is not None:
+            wp, on_dev = C.c_void_p(dev_wires_ptr), 1
+        else:
+            self._w = _a(d.wires if wires is None else wires)     # keep the host array alive
+            wp, on_dev = _p(self._w), 0
+        _chk(L.glp_session_begin(circuit.ctx._h, circuit._h, wp, on_dev, _p(pi) if pi.size else None, C.byref(self._h),
+                                 _p(self.wires_cap), _p(self.public_inputs_hash)))
+
+    def _cap(self, fn, *args):
+        out = np.empty((self._capn, 4), np.uint64)
+        _chk(fn(self._h, *args, _p(out)))
+        return out
+
+    def partial_products(self, betas, gammas):
+        self._b, self._g = _a(betas), _a(gammas)
+        return self._cap(load_library().glp_session_partial_products, _p(self._b), _p(self._g))
+
+    def quotient(self, alphas):
+        self._al = _a(alphas)
+        return self._cap(load_library().glp_session_quotient, _p(self._al))
+
+    def open(self, zeta):
+        L = load_library()
+        out = np.empty((L.glp_num_openings(self.circuit._h), 2), np.uint64)
+        _chk(L.glp_session_open(self._h, _p(_a(zeta)), _p(out)))
+        return out
+
+    def fri_combine(self, alpha):
+        _chk(load_library().glp_session_fri_combine(self._h, _p(_a(alpha))))
+
+    def fri_commit(self):
+        return self._cap(load_library().glp_session_fri_commit)
+
+    def fri_fold(self, beta):
+        _chk(load_library().glp_session_fri_fold(self._h, _p(_a(beta))))
+
+    def fri_final_poly(self):
+        L = load_library()
+        out = np.empty((L.glp_final_poly_len(self.circuit._h), 2), np.uint64)
+        _chk(L.glp_session_fri_final_poly(self._h, _p(out)))
+        return out
+
+    def pow_search(self, sponge_state, pending_inputs, bits):
+        st, pend = _a(sponge_state), _a(pending_inputs)
+        w = C.c_uint64()
+        _chk(load_library().glp_pow_search(self.circuit.ctx._h, _p(st), _p(pend) if pend.size else None, pend.size, int(bits),
+                                           C.byref(w)))
+        return int(w.value)
+
+    def queries(self, pow_witness, indices):
+        idx = _a(indices)
+        _chk(load_library().glp_session_queries(self._h, C.c_uint64(int(pow_witness)), _p(idx), idx.size))
+
+    def proof(self):
+        out = np.zeros(self.circuit.proof_words, np.uint64)
+        _chk(load_library().glp_session_proof(self._h, _p(out)))
+        return out
+
+    def end(self):
+        if getattr(self, "_h", None):
+            load_library().glp_session_end(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.end()
+        except Exception:
+            pass

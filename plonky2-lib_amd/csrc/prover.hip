@@ -276,7 +276,9 @@ __device__ __forceinline__ void acc2_fma(AccLimb &a, u32 v0, u32 v1, u32 v2, u64
 template <int E> __device__ __forceinline__ void acc_add_shifted(Acc160 &w, u64 x) {   // w += x << E
     constexpr int idx = E / 32, sh = E % 32;
     const u64 lo = x << sh;
-    const u32 t0 = (u32)lo, t1 = (u32)(lo >> 32), t2 = sh ? (u32)(x >> (64 - sh)) : 0u;
+    const u32 t0 = (u32)lo, t1 = (u32)(lo >> 32);
+    u32 t2 = 0;
+    if constexpr (sh != 0) t2 = (u32)(x >> (64 - sh));
     u32 *W[5] = {&w.w0, &w.w1, &w.w2, &w.w3, &w.w4};
     u32 c;
     *W[idx] = __builtin_addc(*W[idx], t0, 0u, &c);
@@ -353,7 +355,6 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
             break;
         case GLP_GATE_ARITHMETIC: {
             const u64 c0 = GC[0], c1 = GC[N];
-#pragma unroll 4
             for (u32 i = 0; i < g.p0; i++) {
                 const u64 m0 = W[(size_t)(4 * i) * N], m1 = W[(size_t)(4 * i + 1) * N];
                 const u64 ad = W[(size_t)(4 * i + 2) * N], o = W[(size_t)(4 * i + 3) * N];
@@ -486,6 +487,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 u64 cl = 0, unused_hi = 0;
                 const u64 *limbs = W + (size_t)(5 * nops + 16 * i) * N;
                 LIMBS4_DESC(limbs, 16, 16, k + (15 - _j), cl, unused_hi);
+                (void)unused_hi;
                 k += 16;
                 EMIT(k, sub(cl, res)); k++;
                 EMIT(k, mul(bo, sub(1, bo))); k++;
@@ -498,6 +500,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 const u64 *aux = W + (size_t)(nin + 16 * i) * N;
                 u64 sum = 0, unused_hi = 0;
                 LIMBS4_DESC(aux, 16, 16, k + 1 + _j, sum, unused_hi);
+                (void)unused_hi;
                 EMIT(k, sub(sum, W[(size_t)i * N]));
                 k += 17;
             }
@@ -913,39 +916,63 @@ int zeta_table(glp_ctx *c, ext2 z, int lg, u64 *dev_zt) {
 }
 }  // namespace
 
-static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, const u64 *public_inputs, u64 *proof) {
-    const glp_circuit_desc &d = cc->d;
-    const Layout &L = cc->L;
-    const int lg = (int)d.degree_bits, rb = (int)d.rate_bits;
-    const size_t n = (size_t)1 << lg, N = n << rb;
-    const u32 nch = d.num_challenges, nr = d.num_routed_wires, nw = d.num_wires, nc = d.num_constants;
-    const u32 qdf = d.quotient_degree_factor, npp = d.num_partial_products, capn = 1u << d.cap_height;
-    const u32 nzp = nch * (1 + npp);
-    memset(proof, 0, L.total * 8);
-    Tmp tmp(c);
-
-    u64 pih[4];
-    host_hash_no_pad(public_inputs, d.num_public_inputs, pih);
-    if (d.num_public_inputs) memcpy(proof + L.pis, public_inputs, (size_t)d.num_public_inputs * 8);
-
-    // ---- wires commitment
-    BatchHolder wb;
-    GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b));
+// One proof in flight, cut at the points where the Fiat-Shamir transcript needs something from the device or the device
+// needs a challenge.  glp_prove() drives it with the built-in Challenger; the glp_session_* entry points hand the same
+// steps to a caller that keeps its own transcript (the Rust prover's `Challenger`): SURVEY.md section 8(b).
+struct glp_session {
+    glp_ctx *c;
+    const glp_circuit *cc;
+    const glp_circuit_desc &d;
+    const Layout &L;
+    const int lg, rb;
+    const size_t n, N;
+    const u32 nch, nr, nw, nc, qdf, npp, capn, nzp;
+    Tmp tmp;
+    u64 *owned_wires = nullptr;        // device copy made by begin() when the caller passed host memory
+    const u64 *dev_wires = nullptr;
+    u64 pih[4] = {0, 0, 0, 0};
+    BatchHolder wb, zb, qb;
+    u64 betas[MAXCH] = {}, gammas[MAXCH] = {}, alphas[MAXCH] = {};
+    ext2 zeta = {0, 0}, zeta_next = {0, 0};
+    const glp_batch *ob[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<ext2> open[4], zs_next;
+    u64 *fcoef = nullptr;
+    struct Layer { u64 *vals; u64 *dig; u32 lgL, ab; };
+    std::vector<Layer> layers;
+    u64 *cur = nullptr;
+    int lgcur = 0;
+    u64 shift = GEN;
+    bool layer_open = false;           // a commit-phase layer has been committed and waits for its beta
+    std::vector<u64> proof_words;      // the proof being assembled (glp_proof_words(circuit) words)
     std::vector<u64> cap;
-    GLP_TRY(batch_cap_host(c, wb.b, cap));
-    memcpy(proof + L.caps, cap.data(), capn * 32);
+    enum Stage { S_NEW, S_WIRES, S_ZS, S_QUOTIENT, S_OPEN, S_FRI, S_FINAL, S_DONE } stage = S_NEW;
 
-    Challenger ch;
-    ch.observe(cc->digest, 4);
-    ch.observe(pih, 4);
-    ch.observe(cap.data(), capn * 4);
-    u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
-    for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
-    for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
+    glp_session(glp_ctx *ctx, const glp_circuit *circ)
+        : c(ctx), cc(circ), d(circ->d), L(circ->L), lg((int)circ->d.degree_bits), rb((int)circ->d.rate_bits),
+          n((size_t)1 << circ->d.degree_bits), N(((size_t)1 << circ->d.degree_bits) << circ->d.rate_bits),
+          nch(circ->d.num_challenges), nr(circ->d.num_routed_wires), nw(circ->d.num_wires), nc(circ->d.num_constants),
+          qdf(circ->d.quotient_degree_factor), npp(circ->d.num_partial_products), capn(1u << circ->d.cap_height),
+          nzp(circ->d.num_challenges * (1 + circ->d.num_partial_products)), tmp(ctx) {}
+    ~glp_session() { if (owned_wires) { (void)hipStreamSynchronize(c->stream); c->release(owned_wires); } }
+    u64 *proof() { return proof_words.data(); }
 
-    // ---- partial products and Z
-    BatchHolder zb;
-    {
+    // K1-K4 over the witness; wires cap -> proof, cap
+    int begin(const u64 *wires_dev, const u64 *public_inputs) {
+        GLP_REQUIRE(stage == S_NEW, "session already begun");
+        proof_words.assign(L.total, 0);
+        dev_wires = wires_dev;
+        host_hash_no_pad(public_inputs, d.num_public_inputs, pih);
+        if (d.num_public_inputs) memcpy(proof() + L.pis, public_inputs, (size_t)d.num_public_inputs * 8);
+        GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b));
+        GLP_TRY(batch_cap_host(c, wb.b, cap));
+        memcpy(proof() + L.caps, cap.data(), capn * 32);
+        stage = S_WIRES;
+        return GLP_OK;
+    }
+    // K5 + commitment of Z and the partial products
+    int partial_products(const u64 *betas_in, const u64 *gammas_in) {
+        GLP_REQUIRE(stage == S_WIRES, "partial_products: call after begin");
+        for (u32 i = 0; i < nch; i++) { betas[i] = betas_in[i]; gammas[i] = gammas_in[i]; }
         u64 *zp, *tot;
         const u32 nblocks = nblk(n);
         u64 *dens;
@@ -971,15 +998,15 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
             GLP_HIP(hipGetLastError());
         }
         GLP_TRY(batch_build(c, zp, BATCH_VALUES, nzp, lg, rb, (int)d.cap_height, &zb.b));
+        GLP_TRY(batch_cap_host(c, zb.b, cap));
+        memcpy(proof() + L.caps + capn * 4, cap.data(), capn * 32);
+        stage = S_ZS;
+        return GLP_OK;
     }
-    GLP_TRY(batch_cap_host(c, zb.b, cap));
-    memcpy(proof + L.caps + capn * 4, cap.data(), capn * 32);
-    ch.observe(cap.data(), capn * 4);
-    for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
-
-    // ---- quotient polynomials
-    BatchHolder qb;
-    {
+    // K6 + commitment of the quotient chunks
+    int quotient(const u64 *alphas_in) {
+        GLP_REQUIRE(stage == S_ZS, "quotient: call after partial_products");
+        for (u32 i = 0; i < nch; i++) alphas[i] = alphas_in[i];
         int qdb = 0;
         while ((1u << qdb) < qdf) qdb++;
         const u32 Rq = 1u << qdb, step = 1u << (rb - qdb);
@@ -1051,23 +1078,23 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
             GLP_HIP(hipGetLastError());
         }
         GLP_TRY(batch_build(c, qc, BATCH_COEFFS_BITREV, nch * qdf, lg, rb, (int)d.cap_height, &qb.b));
+        GLP_TRY(batch_cap_host(c, qb.b, cap));
+        memcpy(proof() + L.caps + 2 * capn * 4, cap.data(), capn * 32);
+        stage = S_QUOTIENT;
+        return GLP_OK;
     }
-    GLP_TRY(batch_cap_host(c, qb.b, cap));
-    memcpy(proof + L.caps + 2 * capn * 4, cap.data(), capn * 32);
-    ch.observe(cap.data(), capn * 4);
-
-    const ext2 zeta = ch.get_ext();
-    {
-        ext2 zp = zeta;
-        for (int i = 0; i < lg; i++) zp = e_sqr(zp);
-        if (e_eq(zp, e_from(1))) return set_error(GLP_ERR_PROVE, "Opening point is in the subgroup.");
-    }
-    const ext2 zeta_next = e_scale(zeta, root_of_unity(lg));
-
-    // ---- openings
-    const glp_batch *ob[4] = {cc->cs, wb.b, zb.b, qb.b};
-    std::vector<ext2> open[4], zs_next;
-    {
+    // K7: every committed polynomial at zeta, Z at g zeta; openings -> proof (OpeningSet order)
+    int open_at(ext2 zeta_in) {
+        GLP_REQUIRE(stage == S_QUOTIENT, "open: call after quotient");
+        zeta = zeta_in;
+        {
+            ext2 zp = zeta;
+            for (int i = 0; i < lg; i++) zp = e_sqr(zp);
+            if (e_eq(zp, e_from(1))) return set_error(GLP_ERR_PROVE, "Opening point is in the subgroup.");
+        }
+        zeta_next = e_scale(zeta, root_of_unity(lg));
+        ob[0] = cc->cs; ob[1] = wb.b; ob[2] = zb.b; ob[3] = qb.b;
+        {
         StageScope st(c, "openings", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3] + nzp));
         u64 *zt, *partial;
         GLP_TRY(tmp.get(&zt, 2 * n));
@@ -1081,26 +1108,24 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
         GLP_TRY(open_batch(c, zb.b, zt, partial, all));
         zs_next.assign(all.begin(), all.begin() + nch);
     }
-    {
-        u64 *op = proof + L.openings;
-        size_t o = 0;
-        auto put = [&](ext2 e) { op[o++] = e.a; op[o++] = e.b; };
-        for (u32 k = 0; k < nc + nr; k++) put(open[0][k]);
-        for (u32 k = 0; k < nw; k++) put(open[1][k]);
-        for (u32 k = 0; k < nch; k++) put(open[2][k]);
-        for (u32 k = 0; k < nch; k++) put(zs_next[k]);
-        for (u32 k = 0; k < nch * npp; k++) put(open[2][nch + k]);
-        for (u32 k = 0; k < nch * qdf; k++) put(open[3][k]);
-        const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;
-        const u64 *p_pp = p_zn + 2 * nch, *p_q = p_pp + 2 * nch * npp;
-        ch.observe(p_cs, 2 * (nc + nr)); ch.observe(p_w, 2 * nw); ch.observe(p_zs, 2 * nch);
-        ch.observe(p_pp, 2 * (size_t)nch * npp); ch.observe(p_q, 2 * (size_t)nch * qdf); ch.observe(p_zn, 2 * nch);
+        {
+            u64 *op = proof() + L.openings;
+            size_t o = 0;
+            auto put = [&](ext2 e) { op[o++] = e.a; op[o++] = e.b; };
+            for (u32 k = 0; k < nc + nr; k++) put(open[0][k]);
+            for (u32 k = 0; k < nw; k++) put(open[1][k]);
+            for (u32 k = 0; k < nch; k++) put(open[2][k]);
+            for (u32 k = 0; k < nch; k++) put(zs_next[k]);
+            for (u32 k = 0; k < nch * npp; k++) put(open[2][nch + k]);
+            for (u32 k = 0; k < nch * qdf; k++) put(open[3][k]);
+        }
+        stage = S_OPEN;
+        return GLP_OK;
     }
-
-    // ---- FRI: batch polynomial
-    const ext2 alpha = ch.get_ext();
-    u64 *fcoef;      // [2][n] bit-reversed coefficients of the FRI polynomial
-    GLP_TRY(tmp.get(&fcoef, 2 * n));
+    // K8: alpha-combination of all openings batches, quotient by (X - zeta) / (X - g zeta) -> FRI polynomial
+    int fri_combine(ext2 alpha) {
+        GLP_REQUIRE(stage == S_OPEN, "fri_combine: call after open");
+        GLP_TRY(tmp.get(&fcoef, 2 * n));
     {
         StageScope st(c, "fri_combine", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3]));
         size_t total_cols = 0;
@@ -1132,92 +1157,75 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
         GLP_HIP(hipGetLastError());
     }
 
-    // ---- FRI commit phase
-    struct Layer { u64 *vals; u64 *dig; u32 lgL, ab; };
-    std::vector<Layer> layers;
-    u64 *cur = fcoef;
-    int lgcur = lg;
-    u64 shift = GEN;
-    {
-        StageScope st(c, "fri_commit", 0.0);
-        for (u32 r = 0; r < d.num_reductions; r++) {
-            const u32 ab = d.reduction_arity_bits[r];
-            const u32 lgL = (u32)(lgcur + rb);
-            const size_t Lsz = (size_t)1 << lgL, nleaves = Lsz >> ab;
-            Layer ly;
-            ly.lgL = lgL; ly.ab = ab;
-            GLP_TRY(tmp.get(&ly.vals, 2 * Lsz));
-            GLP_TRY(tmp.get(&ly.dig, merkle_num_digests(nleaves, (int)d.cap_height) * 4));
-            GLP_TRY(lde_coeffs(c, cur, ly.vals, 2, lgcur, rb, shift));
-            if (nleaves <= 8192)
-                hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((nleaves + 15) / 16)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
-                                   (u32)rb, ab);
-            else
-                hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab);
-            GLP_HIP(hipGetLastError());
-            GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height));
-            cap.resize((size_t)capn * 4);
-            GLP_TRY(d2h(c, cap.data(), ly.dig + 4 * merkle_cap_offset(nleaves, (int)d.cap_height), (size_t)capn * 32));
-            memcpy(proof + L.fri_caps + (size_t)r * capn * 4, cap.data(), (size_t)capn * 32);
-            ch.observe(cap.data(), (size_t)capn * 4);
-            layers.push_back(ly);
-            const ext2 beta = ch.get_ext();
-            u64 *nxt;
-            const size_t nnew = ((size_t)1 << lgcur) >> ab;
-            GLP_TRY(tmp.get(&nxt, 2 * nnew));
-            hipLaunchKernelGGL(k_fri_fold, dim3(nblk(nnew)), dim3(256), 0, c->stream, cur, nxt, beta, (u32)lgcur, ab);
-            GLP_HIP(hipGetLastError());
-            cur = nxt; lgcur -= (int)ab;
-            shift = pow(shift, (u64)1 << ab);
-        }
+        cur = fcoef; lgcur = lg; shift = GEN;
+        stage = S_FRI;
+        return GLP_OK;
     }
-    // final polynomial (natural coefficient order)
-    {
+    // K9, first half: LDE of the current polynomial on its coset, Merkle tree over arity-sized leaves; cap -> proof, cap
+    int fri_commit_layer() {
+        GLP_REQUIRE(stage == S_FRI && !layer_open && layers.size() < d.num_reductions, "fri_commit: no layer left or beta pending");
+        StageScope st(c, "fri_commit", 0.0);
+        const u32 r = (u32)layers.size();
+        const u32 ab = d.reduction_arity_bits[r];
+        const u32 lgL = (u32)(lgcur + rb);
+        const size_t Lsz = (size_t)1 << lgL, nleaves = Lsz >> ab;
+        Layer ly;
+        ly.lgL = lgL; ly.ab = ab;
+        GLP_TRY(tmp.get(&ly.vals, 2 * Lsz));
+        GLP_TRY(tmp.get(&ly.dig, merkle_num_digests(nleaves, (int)d.cap_height) * 4));
+        GLP_TRY(lde_coeffs(c, cur, ly.vals, 2, lgcur, rb, shift));
+        if (nleaves <= 8192)
+            hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((nleaves + 15) / 16)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
+                               (u32)rb, ab);
+        else
+            hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab);
+        GLP_HIP(hipGetLastError());
+        GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height));
+        cap.resize((size_t)capn * 4);
+        GLP_TRY(d2h(c, cap.data(), ly.dig + 4 * merkle_cap_offset(nleaves, (int)d.cap_height), (size_t)capn * 32));
+        memcpy(proof() + L.fri_caps + (size_t)r * capn * 4, cap.data(), (size_t)capn * 32);
+        layers.push_back(ly);
+        layer_open = true;
+        return GLP_OK;
+    }
+    // K9, second half: fold the coefficients with beta (arity 2^ab), shift <- shift^arity
+    int fri_fold(ext2 beta) {
+        GLP_REQUIRE(stage == S_FRI && layer_open, "fri_fold: call after fri_commit");
+        StageScope st(c, "fri_commit", 0.0);
+        const u32 ab = layers.back().ab;
+        u64 *nxt;
+        const size_t nnew = ((size_t)1 << lgcur) >> ab;
+        GLP_TRY(tmp.get(&nxt, 2 * nnew));
+        hipLaunchKernelGGL(k_fri_fold, dim3(nblk(nnew)), dim3(256), 0, c->stream, cur, nxt, beta, (u32)lgcur, ab);
+        GLP_HIP(hipGetLastError());
+        cur = nxt; lgcur -= (int)ab;
+        shift = pow(shift, (u64)1 << ab);
+        layer_open = false;
+        return GLP_OK;
+    }
+    // final polynomial (natural coefficient order) -> proof
+    int fri_final_poly() {
+        GLP_REQUIRE(stage == S_FRI && !layer_open && layers.size() == d.num_reductions, "fri_final_poly: reductions not finished");
         const size_t fl = (size_t)1 << lgcur;
         if (fl != L.final_len) return set_error(GLP_ERR_ARG, "reduction_arity_bits inconsistent with degree_bits");
         std::vector<u64> h(2 * fl);
         GLP_TRY(d2h(c, h.data(), cur, h.size() * 8));
         for (size_t p = 0; p < fl; p++) {
             const size_t k = bitrev32((u32)p, lgcur);
-            proof[L.final_poly + 2 * k] = h[p];
-            proof[L.final_poly + 2 * k + 1] = h[fl + p];
+            proof()[L.final_poly + 2 * k] = h[p];
+            proof()[L.final_poly + 2 * k + 1] = h[fl + p];
         }
-        ch.observe(proof + L.final_poly, 2 * fl);
+        stage = S_FINAL;
+        return GLP_OK;
     }
-    // ---- proof of work
-    {
-        StageScope st(c, "fri_pow", 0.0);
-        PowArgs a;
-        memcpy(a.st, ch.st, 96);
-        for (int i = 0; i < ch.nin; i++) a.st[i] = ch.in[i];
-        a.pos = (u32)ch.nin; a.bits = d.proof_of_work_bits;
-        u64 *best;
-        GLP_TRY(tmp.get(&best, 1));
-        a.best = (unsigned long long *)best;
-        const u64 none = ~0ull;
-        u64 found = none;
-        // expected 2^bits tries: size a launch at four times that (a 2^20-candidate launch is 0.6 ms of hashing)
-        const u64 batch = 1ull << std::min<u32>(20, std::max<u32>(14, d.proof_of_work_bits + 2));
-        for (u64 base = 0; found == none; base += batch) {
-            if (base >= (1ull << 40)) return set_error(GLP_ERR_PROVE, "Proof of work failed. This is highly unlikely!");
-            GLP_TRY(h2d(c, best, &none, 8));
-            a.base = base;
-            hipLaunchKernelGGL(k_pow, dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, a);
-            GLP_HIP(hipGetLastError());
-            GLP_TRY(d2h(c, &found, best, 8));
-        }
-        proof[L.pow] = found;
-        ch.observe(&found, 1);
-        const u64 resp = ch.get();
-        if (d.proof_of_work_bits && (resp >> (64 - d.proof_of_work_bits)) != 0)
-            return set_error(GLP_ERR_PROVE, "proof-of-work response check failed");
-    }
-    // ---- query phase
-    {
+    // query phase: leaves and Merkle paths of the four initial oracles and of every commit-phase layer
+    int queries(u64 pow_witness, const u64 *indices, u32 nq) {
+        GLP_REQUIRE(stage == S_FINAL, "queries: call after fri_final_poly");
+        GLP_REQUIRE(nq == d.num_query_rounds, "queries: %u indices, the circuit has %u query rounds", nq, d.num_query_rounds);
+        proof()[L.pow] = pow_witness;
         StageScope st(c, "fri_queries", 0.0);
-        const u32 nq = d.num_query_rounds;
-        std::vector<u64> xi(nq);
-        for (u32 q = 0; q < nq; q++) xi[q] = ch.get() % (u64)N;
+        std::vector<u64> xi(indices, indices + nq);
+        for (u32 q = 0; q < nq; q++) GLP_REQUIRE(xi[q] < (u64)N, "query index %llu outside the LDE domain", (unsigned long long)xi[q]);
         u64 *dev_idx, *dev_buf;
         GLP_TRY(tmp.get(&dev_idx, nq));
         size_t maxbuf = 0;
@@ -1231,11 +1239,11 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
             const u32 ncol = ob[k]->ncols;
             GLP_TRY(merkle_gather_lde_rows(c, ob[k]->lde, ncol, lg, rb, dev_idx, nq, dev_buf));
             GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * ncol * 8));
-            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * ncol, (size_t)ncol * 8);
+            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * ncol, (size_t)ncol * 8);
             off += ncol;
             GLP_TRY(merkle_gather_paths(c, ob[k]->digests, N, (int)d.cap_height, dev_idx, nq, dev_buf));
             GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * L.depth0 * 32));
-            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * L.depth0 * 4, (size_t)L.depth0 * 32);
+            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * L.depth0 * 4, (size_t)L.depth0 * 32);
             off += 4 * (size_t)L.depth0;
         }
         for (size_t r = 0; r < layers.size(); r++) {
@@ -1248,14 +1256,92 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
                                ly.ab, dev_idx, nq, dev_buf);
             GLP_HIP(hipGetLastError());
             GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * arity * 16));
-            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * arity * 2, (size_t)arity * 16);
+            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * arity * 2, (size_t)arity * 16);
             off += 2 * (size_t)arity;
             GLP_TRY(merkle_gather_paths(c, ly.dig, nleaves, (int)d.cap_height, dev_idx, nq, dev_buf));
             GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * depth * 32));
-            for (u32 q = 0; q < nq; q++) memcpy(proof + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * depth * 4, (size_t)depth * 32);
+            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * depth * 4, (size_t)depth * 32);
             off += 4 * (size_t)depth;
         }
+        stage = S_DONE;
+        return GLP_OK;
     }
+};
+
+// K10: smallest witness w >= 0 such that the sponge (state + pending inputs + w) squeezes a value with `bits` leading
+// zeros.  The search covers candidates in increasing order, so the result does not depend on launch geometry.
+static int pow_search(glp_ctx *c, const u64 st[12], const u64 *pending, u32 npending, u32 bits, u64 *witness) {
+    StageScope stg(c, "fri_pow", 0.0);
+    GLP_REQUIRE(npending < 8, "proof of work: %u pending inputs (the rate is 8)", npending);
+    PowArgs a;
+    memcpy(a.st, st, 96);
+    for (u32 i = 0; i < npending; i++) a.st[i] = pending[i];
+    a.pos = npending; a.bits = bits;
+    Tmp tmp(c);
+    u64 *best;
+    GLP_TRY(tmp.get(&best, 1));
+    a.best = (unsigned long long *)best;
+    const u64 none = ~0ull;
+    u64 found = none;
+    // expected 2^bits tries: size a launch at four times that (a 2^20-candidate launch is 0.6 ms of hashing)
+    const u64 batch = 1ull << std::min<u32>(20, std::max<u32>(14, bits + 2));
+    for (u64 base = 0; found == none; base += batch) {
+        if (base >= (1ull << 40)) return set_error(GLP_ERR_PROVE, "Proof of work failed. This is highly unlikely!");
+        GLP_TRY(h2d(c, best, &none, 8));
+        a.base = base;
+        hipLaunchKernelGGL(k_pow, dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, a);
+        GLP_HIP(hipGetLastError());
+        GLP_TRY(d2h(c, &found, best, 8));
+    }
+    *witness = found;
+    return GLP_OK;
+}
+
+// prove(): the session driven by the library's own transcript (plonk/prover.rs order)
+static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, const u64 *public_inputs, u64 *proof) {
+    glp_session s(c, cc);
+    const glp_circuit_desc &d = cc->d;
+    const Layout &L = cc->L;
+    const u32 nch = s.nch, nr = s.nr, nw = s.nw, nc = s.nc, qdf = s.qdf, npp = s.npp, capn = s.capn;
+    GLP_TRY(s.begin(dev_wires, public_inputs));
+    Challenger ch;
+    ch.observe(cc->digest, 4);
+    ch.observe(s.pih, 4);
+    ch.observe(s.cap.data(), capn * 4);
+    u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
+    for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
+    for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
+    GLP_TRY(s.partial_products(betas, gammas));
+    ch.observe(s.cap.data(), capn * 4);
+    for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
+    GLP_TRY(s.quotient(alphas));
+    ch.observe(s.cap.data(), capn * 4);
+    GLP_TRY(s.open_at(ch.get_ext()));
+    {
+        const u64 *op = s.proof() + L.openings;
+        const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;
+        const u64 *p_pp = p_zn + 2 * nch, *p_q = p_pp + 2 * nch * npp;
+        ch.observe(p_cs, 2 * (nc + nr)); ch.observe(p_w, 2 * nw); ch.observe(p_zs, 2 * nch);
+        ch.observe(p_pp, 2 * (size_t)nch * npp); ch.observe(p_q, 2 * (size_t)nch * qdf); ch.observe(p_zn, 2 * nch);
+    }
+    GLP_TRY(s.fri_combine(ch.get_ext()));
+    for (u32 r = 0; r < d.num_reductions; r++) {
+        GLP_TRY(s.fri_commit_layer());
+        ch.observe(s.cap.data(), (size_t)capn * 4);
+        GLP_TRY(s.fri_fold(ch.get_ext()));
+    }
+    GLP_TRY(s.fri_final_poly());
+    ch.observe(s.proof() + L.final_poly, 2 * L.final_len);
+    u64 found;
+    GLP_TRY(pow_search(c, ch.st, ch.in, (u32)ch.nin, d.proof_of_work_bits, &found));
+    ch.observe(&found, 1);
+    const u64 resp = ch.get();
+    if (d.proof_of_work_bits && (resp >> (64 - d.proof_of_work_bits)) != 0)
+        return set_error(GLP_ERR_PROVE, "proof-of-work response check failed");
+    std::vector<u64> xi(d.num_query_rounds);
+    for (u32 q = 0; q < d.num_query_rounds; q++) xi[q] = ch.get() % (u64)s.N;
+    GLP_TRY(s.queries(found, xi.data(), d.num_query_rounds));
+    memcpy(proof, s.proof(), L.total * 8);
     return GLP_OK;
 }
 
@@ -1484,6 +1570,104 @@ int glp_proof_from_bytes(const glp_circuit *cc, const uint8_t *in, size_t len, u
     return GLP_OK;
 }
 
+int glp_session_begin(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, int wires_on_device, const uint64_t *public_inputs,
+                      glp_session **out, uint64_t *wires_cap_out, uint64_t public_inputs_hash_out[4]) {
+    GLP_REQUIRE(c && cc && wires && out && wires_cap_out && public_inputs_hash_out, "null argument");
+    *out = nullptr;
+    GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");
+    GLP_REQUIRE(public_inputs || cc->d.num_public_inputs == 0, "public_inputs is null");
+    GLP_TRY(bind(c));
+    std::unique_ptr<glp_session> s(new glp_session(c, cc));
+    const u64 *dw = wires;
+    if (!wires_on_device) {
+        const size_t tot = (size_t)cc->d.num_wires << cc->d.degree_bits;
+        void *dv = nullptr;
+        GLP_TRY(c->alloc(&dv, tot * 8));
+        s->owned_wires = (u64 *)dv;
+        GLP_TRY(h2d(c, dv, wires, tot * 8));
+        dw = s->owned_wires;
+    }
+    GLP_TRY(s->begin(dw, public_inputs));
+    memcpy(wires_cap_out, s->cap.data(), (size_t)s->capn * 32);
+    memcpy(public_inputs_hash_out, s->pih, 32);
+    *out = s.release();
+    return GLP_OK;
+}
+#define GLP_SESSION_ENTER(S)                         \
+    GLP_REQUIRE((S) != nullptr, "null session");     \
+    GLP_TRY(bind((S)->c))
+int glp_session_partial_products(glp_session *s, const uint64_t *betas, const uint64_t *gammas, uint64_t *zs_cap_out) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(betas && gammas && zs_cap_out, "null argument");
+    GLP_TRY(s->partial_products(betas, gammas));
+    memcpy(zs_cap_out, s->cap.data(), (size_t)s->capn * 32);
+    return GLP_OK;
+}
+int glp_session_quotient(glp_session *s, const uint64_t *alphas, uint64_t *quotient_cap_out) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(alphas && quotient_cap_out, "null argument");
+    GLP_TRY(s->quotient(alphas));
+    memcpy(quotient_cap_out, s->cap.data(), (size_t)s->capn * 32);
+    return GLP_OK;
+}
+size_t glp_num_openings(const glp_circuit *cc) { return cc ? cc->L.nopen : 0; }
+size_t glp_final_poly_len(const glp_circuit *cc) { return cc ? cc->L.final_len : 0; }
+int glp_session_open(glp_session *s, const uint64_t zeta[2], uint64_t *openings_out) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(zeta && openings_out, "null argument");
+    GLP_REQUIRE(zeta[0] < P && zeta[1] < P, "zeta is not canonical");
+    GLP_TRY(s->open_at(e_make(zeta[0], zeta[1])));
+    memcpy(openings_out, s->proof() + s->L.openings, s->L.nopen * 16);
+    return GLP_OK;
+}
+int glp_session_fri_combine(glp_session *s, const uint64_t alpha[2]) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(alpha && alpha[0] < P && alpha[1] < P, "alpha is null or not canonical");
+    return s->fri_combine(e_make(alpha[0], alpha[1]));
+}
+int glp_session_fri_commit(glp_session *s, uint64_t *cap_out) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(cap_out, "null argument");
+    GLP_TRY(s->fri_commit_layer());
+    memcpy(cap_out, s->cap.data(), (size_t)s->capn * 32);
+    return GLP_OK;
+}
+int glp_session_fri_fold(glp_session *s, const uint64_t beta[2]) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(beta && beta[0] < P && beta[1] < P, "beta is null or not canonical");
+    return s->fri_fold(e_make(beta[0], beta[1]));
+}
+int glp_session_fri_final_poly(glp_session *s, uint64_t *coeffs_out) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(coeffs_out, "null argument");
+    GLP_TRY(s->fri_final_poly());
+    memcpy(coeffs_out, s->proof() + s->L.final_poly, s->L.final_len * 16);
+    return GLP_OK;
+}
+int glp_pow_search(glp_ctx *c, const uint64_t sponge_state[12], const uint64_t *pending_inputs, uint32_t num_pending, uint32_t bits,
+                   uint64_t *witness_out) {
+    GLP_REQUIRE(c && sponge_state && witness_out && (pending_inputs || num_pending == 0), "null argument");
+    GLP_REQUIRE(bits <= 40, "proof_of_work_bits=%u: the search stops at 2^40 candidates", bits);
+    GLP_TRY(bind(c));
+    return pow_search(c, sponge_state, pending_inputs, num_pending, bits, witness_out);
+}
+int glp_session_queries(glp_session *s, uint64_t pow_witness, const uint64_t *indices, uint32_t num_indices) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(indices, "null argument");
+    return s->queries(pow_witness, indices, num_indices);
+}
+int glp_session_proof(glp_session *s, uint64_t *proof_out) {
+    GLP_SESSION_ENTER(s);
+    GLP_REQUIRE(proof_out, "null argument");
+    GLP_REQUIRE(s->stage == glp_session::S_DONE, "the proof is not finished (call glp_session_queries first)");
+    memcpy(proof_out, s->proof(), s->L.total * 8);
+    return GLP_OK;
+}
+void glp_session_end(glp_session *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->c->device);
+    delete s;
+}
 int glp_prove_device(glp_ctx *c, const glp_circuit *cc, const uint64_t *dev_wires, const uint64_t *public_inputs, uint64_t *proof_out) {
     GLP_REQUIRE(c && cc && dev_wires && proof_out, "null argument");
     GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");

@@ -209,3 +209,73 @@ def test_unsupported_gate_is_reported(ctx):
     with pytest.raises(glp.GlpError) as e:
         glp.Circuit(ctx, desc)
     assert e.value.code == -3
+
+
+def _stepped_proof(gc, oracle, desc, use_gpu_pow=True):
+    """Drive glp_session_* with an EXTERNAL transcript (the oracle's Challenger, standing in for the Rust prover's) in
+    the order of plonky2's prove_with_partition_witness / fri_proof."""
+    import ctypes
+    nch, n_red = desc.num_challenges, len(desc.reduction_arity_bits)
+    s = glp.Session(gc)
+    ch = oracle.Challenger()
+    ch.observe(np.asarray(desc.circuit_digest, np.uint64))
+    ch.observe(s.public_inputs_hash)
+    ch.observe(s.wires_cap)
+    betas, gammas = ch.get_n(nch), ch.get_n(nch)
+    ch.observe(s.partial_products(betas, gammas))
+    ch.observe(s.quotient(ch.get_n(nch)))
+    op = s.open(ch.get_ext()).reshape(-1)
+    nc_nr, nw = desc.num_constants + desc.num_routed_wires, desc.num_wires
+    npp, qdf = desc.num_partial_products, desc.quotient_degree_factor
+    o = 0
+    parts = {}
+    for name, cnt in (("cs", nc_nr), ("w", nw), ("zs", nch), ("zn", nch), ("pp", nch * npp), ("q", nch * qdf)):
+        parts[name] = op[o:o + 2 * cnt]; o += 2 * cnt
+    for name in ("cs", "w", "zs", "pp", "q", "zn"):          # OpeningSet::to_fri_openings: zeta batch, then zeta*g batch
+        ch.observe(parts[name])
+    s.fri_combine(ch.get_ext())
+    for _ in range(n_red):
+        ch.observe(s.fri_commit())
+        s.fri_fold(ch.get_ext())
+    ch.observe(s.fri_final_poly())
+    # proof of work on the transcript's own sponge: state + pending inputs (oracle struct: st[12], in[8], nin)
+    raw = np.frombuffer(ctypes.string_at(ch._buf, 8 * 21), dtype=np.uint64)
+    nin = int(np.frombuffer(ctypes.string_at(ctypes.addressof(ch._buf) + 8 * 20, 4), dtype=np.int32)[0])
+    w = s.pow_search(raw[:12], raw[12:12 + nin], desc.proof_of_work_bits)
+    ch.observe([w])
+    resp = ch.get()
+    assert resp >> (64 - desc.proof_of_work_bits) == 0
+    N = 1 << (desc.degree_bits + desc.rate_bits)
+    s.queries(w, [ch.get() % N for _ in range(desc.num_query_rounds)])
+    proof = s.proof()
+    s.end()
+    return proof
+
+
+@pytest.mark.parametrize("lg,cfg", [(6, "rec"), (12, "ecc")])
+def test_stepped_session_equals_prove(ctx, oracle, lg, cfg):
+    """The stage-level C ABI driven by a caller-side transcript yields the identical proof as glp_prove (whose words
+    the other tests pin against the oracle prover), and the oracle verifier accepts it."""
+    config = synth.Config.standard_ecc_config() if cfg == "ecc" else synth.Config.standard_recursion_config()
+    pi = [3, 1 << 40, 0xFFFFFFFF00000000]
+    desc = synth.arith_circuit(lg, config, seed=77, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi))
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    ref = gc.prove()
+    got = _stepped_proof(gc, oracle, desc)
+    assert (got == ref).all(), "first mismatch at word %d" % int(np.argmax(got != ref))
+    assert oc.verify(got) == 0
+
+
+def test_stepped_session_enforces_order(ctx):
+    desc = synth.arith_circuit(5, synth.Config.standard_recursion_config(), seed=3)
+    gc = glp.Circuit(ctx, desc)
+    s = glp.Session(gc)
+    with pytest.raises(glp.GlpError):
+        s.quotient([1] * desc.num_challenges)          # partial_products must come first
+    with pytest.raises(glp.GlpError):
+        s.proof()                                      # nothing to hand out yet
+    s.partial_products([5] * desc.num_challenges, [7] * desc.num_challenges)
+    with pytest.raises(glp.GlpError):
+        s.fri_commit()
+    s.end()

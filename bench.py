@@ -209,7 +209,7 @@ def main():
         stages[key][1] += 1
     stage_out = {}
     for k in order:
-        ms_avg = stages[k][0] / stages[k][1]
+        ms_avg = stages[k][0] / max(a.steps, 1)      # per proof (a stage may be recorded several times per proof)
         stage_out[k] = {"ms": round(ms_avg, 4), "alg_GB": round(stages[k][2] / 1e9, 4),
                         "GBps": round(stages[k][2] / 1e9 / (ms_avg / 1e3), 1) if ms_avg > 0 and stages[k][2] else None}
     dom = max(order, key=lambda k: stage_out[k]["ms"])

@@ -1599,6 +1599,7 @@ int glp_session_begin(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, 
 int glp_session_partial_products(glp_session *s, const uint64_t *betas, const uint64_t *gammas, uint64_t *zs_cap_out) {
     GLP_SESSION_ENTER(s);
     GLP_REQUIRE(betas && gammas && zs_cap_out, "null argument");
+    for (u32 i = 0; i < s->nch; i++) GLP_REQUIRE(betas[i] < P && gammas[i] < P, "challenge %u is not a canonical field element", i);
     GLP_TRY(s->partial_products(betas, gammas));
     memcpy(zs_cap_out, s->cap.data(), (size_t)s->capn * 32);
     return GLP_OK;
@@ -1606,6 +1607,7 @@ int glp_session_partial_products(glp_session *s, const uint64_t *betas, const ui
 int glp_session_quotient(glp_session *s, const uint64_t *alphas, uint64_t *quotient_cap_out) {
     GLP_SESSION_ENTER(s);
     GLP_REQUIRE(alphas && quotient_cap_out, "null argument");
+    for (u32 i = 0; i < s->nch; i++) GLP_REQUIRE(alphas[i] < P, "challenge %u is not a canonical field element", i);
     GLP_TRY(s->quotient(alphas));
     memcpy(quotient_cap_out, s->cap.data(), (size_t)s->capn * 32);
     return GLP_OK;

@@ -275,6 +275,8 @@ def test_stepped_session_enforces_order(ctx):
         s.quotient([1] * desc.num_challenges)          # partial_products must come first
     with pytest.raises(glp.GlpError):
         s.proof()                                      # nothing to hand out yet
+    with pytest.raises(glp.GlpError):
+        s.partial_products([0xFFFFFFFF00000001] * desc.num_challenges, [7] * desc.num_challenges)   # p itself: not canonical
     s.partial_products([5] * desc.num_challenges, [7] * desc.num_challenges)
     with pytest.raises(glp.GlpError):
         s.fri_commit()

@@ -79,14 +79,35 @@ def valu_roofline(stage_key, ms, log_n, ncols):
             "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "T lane-ops/s", "frac": ach / peak}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box gives one
+    GPU's share of the host, not all of it; omp_get_max_threads() reports the machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(sample_log_n, full_log_n):
     """Times the oracle (CPU restatement of plonky2's prove(), kind="port") on a bounded sample of the
-    same workload: the same synthetic ECDSA-shaped circuit with 2^sample_log_n rows.  Commit stages
-    use all host cores through OpenMP; the remaining stages of the port are single-threaded."""
+    same workload: the same synthetic ECDSA-shaped circuit with 2^sample_log_n rows, OpenMP over the cores this
+    process may use (`cores` = that number).  The port is a plain restatement (radix-2 FFT per column, naive Poseidon,
+    extension-field gate evaluation), several times slower than an optimised CPU prover would be: a baseline, not a target."""
     from oracle import oracle
     import plonky2_lib_amd.synth as synth
     oracle.build()
-    cores = oracle.max_threads()
+    cores = max(1, min(oracle.max_threads(), usable_cores()))
+    oracle.set_threads(cores)
     desc = synth.ecdsa_shape_circuit(sample_log_n, seed=SEED)
     oc = oracle.OracleCircuit(desc)
     t0 = time.perf_counter()

@@ -201,6 +201,12 @@ __device__ __forceinline__ u64 add_cnc(u64 a, u64 b) {
     hi = __builtin_addc(hi, 0u, c2, &c2);
     return ((u64)hi << 32) | lo;
 }
+// x (any u64) times a 32-bit constant -> non-canonical: two multiply-adds and one fold
+__device__ __forceinline__ u64 mul_small_nc(u64 x, u32 g) {
+    const u64 lo = (u64)(u32)x * g;
+    const u64 hi = (u64)(u32)(x >> 32) * g + (lo >> 32);
+    return fold96_nc((hi << 32) | (u32)lo, (u32)(hi >> 32));
+}
 // canonical product through the limb form
 __device__ __forceinline__ u64 mul_c(u64 a, u64 b) { return canon(mul_nc(a, b)); }
 // x * 2^E mod p for a compile-time 0 < E < 96 (x any u64) -> canonical.  Every 64th root of unity of

@@ -40,6 +40,7 @@ struct glp_circuit {
     u64 digest[4];
     DevGate *dev_gates = nullptr;
     u64 *dev_k_is = nullptr;
+    u32 k_ratio = 0;               // g if k_is[j] = g^j for all j with g < 2^32 (then the quotient kernel chains by g), else 0
     u64 *dev_sigmas = nullptr;     // [nr][n] values on H (natural order), for the partial products
     glp_batch *cs = nullptr;       // constants_sigmas_commitment
     std::vector<u64> cs_cap;
@@ -304,6 +305,7 @@ struct QArgs {
     u64 shift_r[MAXR], zh[MAXR], zh_inv[MAXR];   // per evaluated plane
     u64 w_n, n_field;
     u32 lg, rb, step, nc, nsel, nr, nw, nch, npp, qdf, num_gates, nterms, many_selectors, gate_mode;
+    u32 k_ratio;                    // != 0: k_is[j] = k_ratio^j (plonky2's get_unique_coset_shifts: powers of the generator 7)
 };
 // Contribution of ONE gate at one point: filter(selector) * sum_k constraint_k * alpha_c^(k0 + k), added into acc[c].
 // TYPE >= 0 compiles a single gate body (per-gate kernels: small register footprint, high occupancy); TYPE = -1
@@ -614,6 +616,8 @@ __global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
         const u64 t = mul(l0, sub(zx[c], 1));
         _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + c]);
     }
+    u64 bkx[MAXCH];                                    // beta_c k_j x for the next wire j (k_ratio path)
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) bkx[c] = mul_nc(a.betas[c], x);
     for (u32 chunk = 0; chunk < nchunks; chunk++) {
         u64 num[MAXCH], den[MAXCH];
         _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
@@ -628,11 +632,16 @@ __global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
                 if (jb + t < j1) {
                     // lazy chain: the running products and the beta terms stay non-canonical u64 (mul_nc takes any
                     // u64); only w + gamma is a canonical addition, shared by numerator and denominator
-                    const u64 kx = mul_nc(a.k_is[jb + t], x);
+                    // beta k_j x: with k_j = g^j (g < 2^32, how plonky2 picks the coset shifts) it is the previous
+                    // wire's value times g -- two multiply-adds and a fold instead of two full multiplications
+                    u64 kx = 0;
+                    if (!a.k_ratio) kx = mul_nc(a.k_is[jb + t], x);
                     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
                         const u64 wg = add(w8[t], a.gammas[c]);
-                        num[c] = mul_nc(num[c], add_cnc(wg, mul_nc(a.betas[c], kx)));
+                        const u64 bk = a.k_ratio ? bkx[c] : mul_nc(a.betas[c], kx);
+                        num[c] = mul_nc(num[c], add_cnc(wg, bk));
                         den[c] = mul_nc(den[c], add_cnc(wg, mul_nc(a.betas[c], s8[t])));
+                        if (a.k_ratio) bkx[c] = mul_small_nc(bkx[c], a.k_ratio);
                     }
                 }
         }
@@ -1021,7 +1030,7 @@ struct glp_session {
         GLP_TRY(tmp.get(&qc, (size_t)nch * Rq * n));
         QArgs a;
         a.cs = cc->cs->lde; a.wl = wb.b->lde; a.zl = zb.b->lde; a.out = qv;
-        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; a.apow = dev_apow;
+        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; a.apow = dev_apow; a.k_ratio = cc->k_ratio;
         for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
         memcpy(a.pih, pih, 32);
         const u64 WN = root_of_unity(lg + rb), gn = pow(GEN, (u64)n), wR = root_of_unity(rb);
@@ -1474,6 +1483,11 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
     cc->d = d;
     cc->gates.assign(d.gates, d.gates + d.num_gates);
     cc->k_is.assign(d.k_is, d.k_is + d.num_routed_wires);
+    if (cc->k_is.size() >= 2 && cc->k_is[0] == 1 && cc->k_is[1] > 1 && cc->k_is[1] < (1ull << 32)) {
+        cc->k_ratio = (u32)cc->k_is[1];
+        for (size_t j = 1; j < cc->k_is.size(); j++)
+            if (cc->k_is[j] != mul(cc->k_is[j - 1], (u64)cc->k_ratio)) { cc->k_ratio = 0; break; }
+    }
     cc->d.gates = cc->gates.data(); cc->d.k_is = cc->k_is.data(); cc->d.constants = nullptr; cc->d.sigmas = nullptr;
     make_layout(cc->d, cc->L);
     const size_t n = (size_t)1 << d.degree_bits;

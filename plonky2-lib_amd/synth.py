@@ -168,7 +168,9 @@ class Builder:
         c.rate_bits, c.cap_height = cfg.rate_bits, cfg.cap_height
         c.proof_of_work_bits, c.num_query_rounds = cfg.proof_of_work_bits, cfg.num_query_rounds
         c.reduction_arity_bits = cfg.reduction_arity_bits(lg)
-        c.k_is = gl.powers(7, cfg.num_routed_wires)
+        c.k_is = gl.powers(7, cfg.num_routed_wires)          # get_unique_coset_shifts: powers of the generator
+        if getattr(cfg, "scramble_k_is", False):               # test hook: any distinct coset shifts are valid
+            c.k_is = np.ascontiguousarray(c.k_is[::-1])
         subgroup = gl.powers(gl.root_of_unity(lg), n)
         c.constants = consts
         c.sigmas = gl.mul(c.k_is[self.sig_col], subgroup[self.sig_row])

@@ -73,6 +73,16 @@ def test_prove_parity_config_sweep(ctx, oracle, kw):
     _check(ctx, oracle, desc)
 
 
+def test_prove_parity_non_geometric_coset_shifts(ctx, oracle):
+    """k_is that are NOT 1, g, g^2, ... take the generic path of the permutation kernel (the chained multiply-by-g
+    shortcut only applies to plonky2's own choice of shifts)."""
+    config = synth.Config.standard_recursion_config()
+    config.scramble_k_is = True
+    desc = synth.arith_circuit(7, config, seed=41)
+    assert int(desc.k_is[0]) != 1
+    _check(ctx, oracle, desc)
+
+
 def test_prove_parity_public_inputs(ctx, oracle):
     pi = np.array([5, 6, 7, 8, 9], np.uint64)
     desc = synth.arith_circuit(7, seed=9, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi))

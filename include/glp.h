@@ -240,6 +240,13 @@ GLP_API int glp_session_queries(glp_session *s, uint64_t pow_witness, const uint
 GLP_API int glp_session_proof(glp_session *s, uint64_t *proof_out /* glp_proof_words(circuit) */);
 GLP_API void glp_session_end(glp_session *s);
 
+/* `CircuitData::verify(proof)` [REF src/ecdsa/gadgets/ecdsa.rs:352, src/zkdsa/circuits/mod.rs:346]: checks a proof in
+ * the word layout above against the circuit (gate table, coset shifts, digest, constants/sigmas cap): transcript,
+ * proof of work, vanishing polynomial at zeta against the quotient openings, every FRI query (Merkle paths, initial
+ * combination, arity-2^k consistency, final polynomial).  Host computation (a few thousand Poseidon permutations), no
+ * device work.  GLP_OK = accepted; GLP_ERR_PROVE with the reason in glp_last_error() = rejected. */
+GLP_API int glp_verify(const glp_circuit *circuit, const uint64_t *proof_words);
+
 /* plonky2 `ProofWithPublicInputs::to_bytes()` (util/serialization.rs `Buffer::write_proof_with_public_inputs`):
  * every field element as 8 little-endian bytes in the word order above, plus the one-byte sibling
  * count that `write_merkle_proof` puts in front of every Merkle path.  This is the wire format the

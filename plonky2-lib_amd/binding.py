@@ -124,6 +124,7 @@ def load_library():
         "glp_session_queries": [vp, C.c_uint64, vp, C.c_uint32],
         "glp_session_proof": [vp, vp],
         "glp_session_end": [vp],
+        "glp_verify": [vp, vp],
     })
     for name in ("glp_num_openings", "glp_final_poly_len"):
         getattr(L, name).restype = sz
@@ -378,6 +379,16 @@ class Circuit:
         proof = np.zeros(self.proof_words, np.uint64)
         _chk(load_library().glp_prove(self.ctx._h, self._h, _p(w), _p(pi) if pi.size else None, _p(proof)))
         return proof
+
+    def verify(self, proof_words):
+        """`data.verify(proof)`: True if accepted; raises nothing on rejection (reason: `last_error()`)."""
+        L = load_library()
+        rc = L.glp_verify(self._h, _p(_a(proof_words)))
+        if rc == 0:
+            return True
+        if rc == -5:          # GLP_ERR_PROVE: a well-formed call, the proof is rejected
+            return False
+        _chk(rc)
 
     def proof_to_bytes(self, proof_words):
         """`ProofWithPublicInputs::to_bytes()`."""

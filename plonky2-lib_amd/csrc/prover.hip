@@ -18,61 +18,9 @@
 #include "merkle.h"
 #include "ntt.h"
 #include "poseidon.h"
+#include "prover_types.h"
 
-using namespace glp;
-using namespace glf;
-
-constexpr int MAXCH = 4;      // num_challenges supported
-constexpr int MAXR = 16;      // 2^rate_bits supported
-
-struct DevGate { u32 type, selector_index, group_start, group_end, row, num_constraints, p0, p1; };
-
-struct Layout {
-    size_t caps, openings, fri_caps, queries, final_poly, pow, pis, total, nopen, query_stride;
-    u32 oracle_cols[4], depth0, step_depth[16], final_len;
-};
-
-struct glp_circuit {
-    glp_ctx *ctx = nullptr;
-    glp_circuit_desc d;            // scalars + host copies below
-    std::vector<glp_gate> gates;
-    std::vector<u64> k_is;
-    u64 digest[4];
-    DevGate *dev_gates = nullptr;
-    u64 *dev_k_is = nullptr;
-    u32 k_ratio = 0;               // g if k_is[j] = g^j for all j with g < 2^32 (then the quotient kernel chains by g), else 0
-    u64 *dev_sigmas = nullptr;     // [nr][n] values on H (natural order), for the partial products
-    glp_batch *cs = nullptr;       // constants_sigmas_commitment
-    std::vector<u64> cs_cap;
-    Layout L;
-};
-
-// ------------------------------------------------------------------------------------------ transcript
 namespace {
-struct Challenger {   // iop/challenger.rs, overwrite-mode duplex sponge; challenges pop from the END of the rate
-    u64 st[12]; u64 in[8]; int nin = 0; u64 out[8]; int nout = 0;
-    Challenger() { memset(st, 0, sizeof(st)); }
-    void duplex() {
-        for (int i = 0; i < nin; i++) st[i] = in[i];
-        nin = 0;
-        pos::permute(st);
-        memcpy(out, st, 64); nout = 8;
-    }
-    void observe(const u64 *e, size_t n) {
-        for (size_t i = 0; i < n; i++) { nout = 0; in[nin++] = e[i]; if (nin == 8) duplex(); }
-    }
-    u64 get() { if (nin > 0 || nout == 0) duplex(); return out[--nout]; }
-    ext2 get_ext() { u64 a = get(); u64 b = get(); return e_make(a, b); }
-};
-void host_hash_no_pad(const u64 *in, size_t len, u64 out[4]) {
-    u64 st[12] = {0};
-    for (size_t off = 0; off < len; off += 8) {
-        size_t c = std::min<size_t>(8, len - off);
-        for (size_t i = 0; i < c; i++) st[i] = in[off + i];
-        pos::permute(st);
-    }
-    memcpy(out, st, 32);
-}
 void make_layout(const glp_circuit_desc &c, Layout &L) {
     const u32 cap = 1u << c.cap_height, nch = c.num_challenges;
     memset(&L, 0, sizeof(L));

@@ -46,6 +46,7 @@ def _check(ctx, oracle, desc):
         assert (got[sl] == ref[sl]).all(), "first mismatch in section %s at word %d" % (
             name, sl.start + int(np.argmax(got[sl] != ref[sl])))
     assert oc.verify(got) == 0
+    assert gc.verify(got) and gc.verify(ref)          # the library's own verifier accepts both provers' proofs
     return oc, gc, got
 
 
@@ -275,6 +276,39 @@ def test_stepped_session_equals_prove(ctx, oracle, lg, cfg):
     got = _stepped_proof(gc, oracle, desc)
     assert (got == ref).all(), "first mismatch at word %d" % int(np.argmax(got != ref))
     assert oc.verify(got) == 0
+
+
+def test_verifier_rejects_tampered_proofs(ctx, oracle):
+    """glp_verify (host-side restatement of plonk/verifier.rs + fri/verifier.rs, independent of the oracle) must reject a
+    proof with any single word changed, section by section, and agree with the oracle's verifier on each."""
+    desc = synth.ecdsa_shape_circuit(6, seed=5)
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    proof = gc.prove()
+    assert gc.verify(proof) and oc.verify(proof) == 0
+    sec = _sections(oc, desc)
+    rng = np.random.default_rng(7)
+    L = len(proof)
+    picks = [sl.start + int(rng.integers(0, max(1, (sl.stop or L) - sl.start))) for sl in sec.values()]
+    picks += [L - 1 - len(desc.public_inputs) if len(desc.public_inputs) else L - 1, L - 2]     # pow witness region / tail
+    picks += [int(x) for x in rng.integers(0, L, 24)]
+    for pos in picks:
+        bad = proof.copy()
+        bad[pos] = (int(bad[pos]) + 1) % 0xFFFFFFFF00000001
+        assert not gc.verify(bad), "tampered word %d accepted" % pos
+        assert oc.verify(bad) != 0
+    bad = proof.copy()
+    bad[0] = 0xFFFFFFFF00000001          # not canonical
+    assert not gc.verify(bad)
+
+
+def test_verifier_rejects_unsatisfied_witness(ctx, oracle):
+    desc = synth.arith_circuit(7, seed=11)
+    w = desc.wires.copy()
+    w[7, 50] = np.uint64((int(w[7, 50]) + 1) % glp.P)        # break one ArithmeticGate row
+    gc = glp.Circuit(ctx, desc)
+    assert not gc.verify(gc.prove(wires=w))
+    assert gc.verify(gc.prove())
 
 
 def test_stepped_session_enforces_order(ctx):

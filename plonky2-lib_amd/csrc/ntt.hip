@@ -362,18 +362,6 @@ __global__ __launch_bounds__(TPB) void k_intt_contig(const u64 *__restrict__ in,
     }
 }
 
-// Outer twiddle of the three-pass transform: data [planes][A'][M]; element (plane, pbo, q) *= t1[rsel][pbo][q >> 10] * t0[pbo][q & 1023]
-// with rsel = plane % R.  grid = (M / 256, planes * A')
-__global__ __launch_bounds__(256) void k_big_twiddle(u64 *__restrict__ data, const u64 *__restrict__ t0, const u64 *__restrict__ t1,
-                                                     int lgAo, int lgM, int R) {
-    const size_t M = (size_t)1 << lgM;
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const u32 blk = blockIdx.y, pbo = blk & ((1u << lgAo) - 1), plane = blk >> lgAo, r = plane % (u32)R;
-    const u64 f = mul_nc(t1[(((size_t)r << lgAo) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]);
-    u64 *p = data + (size_t)blk * M + q;
-    *p = mul_c(*p, f);
-}
-
 __global__ void k_bitrev_copy(const u64 *__restrict__ in, u64 *__restrict__ out, int lg) {
     const size_t n = (size_t)1 << lg;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,6 +434,90 @@ template <bool INV> __device__ __forceinline__ void dft16_dif(u64 x[16]) {
     for (int j = 0; j < 16; j += 2) bf_dif<INV, 0>(x[j], x[j + 1]);
 }
 __device__ __forceinline__ int brev4(int x) { return ((x & 1) << 3) | ((x & 2) << 1) | ((x & 4) >> 1) | ((x & 8) >> 3); }
+
+// 2^L-point DFTs (L <= 4) on registers: the first L stages of dft16_dit / the last L stages of dft16_dif -- the twiddle
+// of a radix-2 stage depends on the stage, not on the transform length, and all of them are powers of w_16 (shifts).
+template <bool INV, int L> __device__ __forceinline__ void dft_small_dit(u64 *x) {      // bit-reversed in -> natural out
+    constexpr int S = 1 << L;
+#pragma unroll
+    for (int j = 0; j < S; j += 2) bf_dit<INV, 0>(x[j], x[j + 1]);
+    if constexpr (L >= 2) {
+#pragma unroll
+        for (int b = 0; b < S; b += 4) { bf_dit<INV, 0>(x[b], x[b + 2]); bf_dit<INV, 4>(x[b + 1], x[b + 3]); }
+    }
+    if constexpr (L >= 3) {
+#pragma unroll
+        for (int b = 0; b < S; b += 8) {
+            bf_dit<INV, 0>(x[b], x[b + 4]); bf_dit<INV, 2>(x[b + 1], x[b + 5]);
+            bf_dit<INV, 4>(x[b + 2], x[b + 6]); bf_dit<INV, 6>(x[b + 3], x[b + 7]);
+        }
+    }
+    if constexpr (L >= 4) {
+        bf_dit<INV, 0>(x[0], x[8]); bf_dit<INV, 1>(x[1], x[9]); bf_dit<INV, 2>(x[2], x[10]); bf_dit<INV, 3>(x[3], x[11]);
+        bf_dit<INV, 4>(x[4], x[12]); bf_dit<INV, 5>(x[5], x[13]); bf_dit<INV, 6>(x[6], x[14]); bf_dit<INV, 7>(x[7], x[15]);
+    }
+}
+template <bool INV, int L> __device__ __forceinline__ void dft_small_dif(u64 *x) {      // natural in -> bit-reversed out
+    constexpr int S = 1 << L;
+    if constexpr (L >= 4) {
+        bf_dif<INV, 0>(x[0], x[8]); bf_dif<INV, 1>(x[1], x[9]); bf_dif<INV, 2>(x[2], x[10]); bf_dif<INV, 3>(x[3], x[11]);
+        bf_dif<INV, 4>(x[4], x[12]); bf_dif<INV, 5>(x[5], x[13]); bf_dif<INV, 6>(x[6], x[14]); bf_dif<INV, 7>(x[7], x[15]);
+    }
+    if constexpr (L >= 3) {
+#pragma unroll
+        for (int b = 0; b < S; b += 8) {
+            bf_dif<INV, 0>(x[b], x[b + 4]); bf_dif<INV, 2>(x[b + 1], x[b + 5]);
+            bf_dif<INV, 4>(x[b + 2], x[b + 6]); bf_dif<INV, 6>(x[b + 3], x[b + 7]);
+        }
+    }
+    if constexpr (L >= 2) {
+#pragma unroll
+        for (int b = 0; b < S; b += 4) { bf_dif<INV, 0>(x[b], x[b + 2]); bf_dif<INV, 4>(x[b + 1], x[b + 3]); }
+    }
+#pragma unroll
+    for (int j = 0; j < S; j += 2) bf_dif<INV, 0>(x[j], x[j + 1]);
+}
+
+// Outer pass of the three-pass transform (n = A' * 2^20, A' = 2^L <= 16): one thread owns position q of all A' blocks
+// of a plane, so the outer twiddle and the A'-point transform happen in registers in ONE sweep over the data (the
+// two-kernel form -- twiddle sweep, then 4-row LDS tiles -- moved the LDE through HBM twice and ran the DFT on 64-element
+// tiles).  Forward (DIF = false): x[pbo] *= t1[r][pbo][q >> 10] * t0[pbo][q & 1023], then DIT over pbo (rows stored
+// bit-reversed).  Inverse: DIF over pbo, then the twiddle (1/A' folded into t1).  grid = (M / 256, planes)
+template <bool DIF, int L>
+__global__ __launch_bounds__(256) void k_outer(const u64 *__restrict__ in, u64 *__restrict__ out, const u64 *__restrict__ t0,
+                                               const u64 *__restrict__ t1, int lgM, int R) {
+    constexpr int A = 1 << L;
+    const size_t M = (size_t)1 << lgM;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 plane = blockIdx.y, r = plane % (u32)R;
+    const size_t base = ((size_t)plane << L) * M + q;
+    u64 x[A];
+#pragma unroll
+    for (int pbo = 0; pbo < A; pbo++) x[pbo] = in[base + (size_t)pbo * M];
+    if (!DIF) {
+#pragma unroll
+        for (int pbo = 0; pbo < A; pbo++)
+            x[pbo] = mul_c(x[pbo], mul_nc(t1[(((size_t)r << L) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]));
+        dft_small_dit<false, L>(x);
+    } else {
+        dft_small_dif<true, L>(x);
+#pragma unroll
+        for (int pbo = 0; pbo < A; pbo++)
+            x[pbo] = mul_c(x[pbo], mul_nc(t1[(((size_t)r << L) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]));
+    }
+#pragma unroll
+    for (int pbo = 0; pbo < A; pbo++) out[base + (size_t)pbo * M] = x[pbo];
+}
+template <bool DIF>
+static void launch_outer(glp_ctx *c, const u64 *in, u64 *out, const u64 *t0, const u64 *t1, int lgAo, int lgM, int R, u32 planes) {
+    const dim3 g((unsigned)(((size_t)1 << lgM) / 256), planes), b(256);
+    switch (lgAo) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 1>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 2>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 3>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 4>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    }
+}
 
 constexpr int R16_LDS = 17 * 256;       // 16 x 16 x 16 tile, rows of 16 padded to 17 (bank spread for stride-16 reads)
 
@@ -661,11 +733,7 @@ int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int l
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<false>), dim3((1u << in->lgB) / NTT_STRIDED_W, (ncols * R) << lgAo), dim3(TPB), 0,
                            c->stream, dev_lde, dev_lde, in->tw4096, lgM, in->lgB);
         GLP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_big_twiddle, dim3((1u << lgM) / 256, (ncols * R) << lgAo), dim3(256), 0, c->stream, dev_lde, lp->t0, lp->t1,
-                           lgAo, lgM, R);
-        GLP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), dim3((1u << lgM) / NTT_STRIDED_W, ncols * R), dim3(TPB), 0, c->stream, dev_lde,
-                           dev_lde, np->tw_Ao, lg, lgAo, lgM);
+        launch_outer<false>(c, dev_lde, dev_lde, lp->t0, lp->t1, lgAo, lgM, R, ncols * R);
         GLP_HIP(hipGetLastError());
         return GLP_OK;
     }
@@ -702,11 +770,7 @@ int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u3
     if (lg > NTT_2PASS_LG) {
         const NttPlan *in = np->inner;
         const int lgAo = np->lgAo, lgM = NTT_2PASS_LG;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), dim3((1u << lgM) / NTT_STRIDED_W, ncols), dim3(TPB), 0, c->stream, dev_values,
-                           dev_coeffs, np->itw_Ao, lg, lgAo, lgM);
-        GLP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_big_twiddle, dim3((1u << lgM) / 256, ncols << lgAo), dim3(256), 0, c->stream, dev_coeffs, np->it0, np->it1, lgAo,
-                           lgM, 1);
+        launch_outer<true>(c, dev_values, dev_coeffs, np->it0, np->it1, lgAo, lgM, 1, ncols);
         GLP_HIP(hipGetLastError());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<true>), dim3((1u << in->lgB) / NTT_STRIDED_W, ncols << lgAo), dim3(TPB), 0, c->stream,
                            dev_coeffs, dev_coeffs, in->itw4096, lgM, in->lgB);

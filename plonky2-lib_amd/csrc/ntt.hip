@@ -483,7 +483,8 @@ template <bool INV, int L> __device__ __forceinline__ void dft_small_dif(u64 *x)
 // two-kernel form -- twiddle sweep, then 4-row LDS tiles -- moved the LDE through HBM twice and ran the DFT on 64-element
 // tiles).  Forward (DIF = false): x[pbo] *= t1[r][pbo][q >> 10] * t0[pbo][q & 1023], then DIT over pbo (rows stored
 // bit-reversed).  Inverse: DIF over pbo, then the twiddle (1/A' folded into t1).  grid = (M / 256, planes)
-template <bool DIF, int L>
+// TW = false: no twiddle, the plain strided pass of a two-pass transform with A <= 16 rows (lg 13..16).
+template <bool DIF, int L, bool TW>
 __global__ __launch_bounds__(256) void k_outer(const u64 *__restrict__ in, u64 *__restrict__ out, const u64 *__restrict__ t0,
                                                const u64 *__restrict__ t1, int lgM, int R) {
     constexpr int A = 1 << L;
@@ -495,27 +496,31 @@ __global__ __launch_bounds__(256) void k_outer(const u64 *__restrict__ in, u64 *
 #pragma unroll
     for (int pbo = 0; pbo < A; pbo++) x[pbo] = in[base + (size_t)pbo * M];
     if (!DIF) {
+        if constexpr (TW) {
 #pragma unroll
-        for (int pbo = 0; pbo < A; pbo++)
-            x[pbo] = mul_c(x[pbo], mul_nc(t1[(((size_t)r << L) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]));
+            for (int pbo = 0; pbo < A; pbo++)
+                x[pbo] = mul_c(x[pbo], mul_nc(t1[(((size_t)r << L) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]));
+        }
         dft_small_dit<false, L>(x);
     } else {
         dft_small_dif<true, L>(x);
+        if constexpr (TW) {
 #pragma unroll
-        for (int pbo = 0; pbo < A; pbo++)
-            x[pbo] = mul_c(x[pbo], mul_nc(t1[(((size_t)r << L) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]));
+            for (int pbo = 0; pbo < A; pbo++)
+                x[pbo] = mul_c(x[pbo], mul_nc(t1[(((size_t)r << L) + pbo) * 1024 + (q >> 10)], t0[(size_t)pbo * 1024 + (q & 1023)]));
+        }
     }
 #pragma unroll
     for (int pbo = 0; pbo < A; pbo++) out[base + (size_t)pbo * M] = x[pbo];
 }
-template <bool DIF>
+template <bool DIF, bool TW>
 static void launch_outer(glp_ctx *c, const u64 *in, u64 *out, const u64 *t0, const u64 *t1, int lgAo, int lgM, int R, u32 planes) {
     const dim3 g((unsigned)(((size_t)1 << lgM) / 256), planes), b(256);
     switch (lgAo) {
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 1>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 2>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 3>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 4>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 1, TW>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 2, TW>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 3, TW>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_outer<DIF, 4, TW>), g, b, 0, c->stream, in, out, t0, t1, lgM, R); break;
     }
 }
 
@@ -733,7 +738,7 @@ int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int l
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<false>), dim3((1u << in->lgB) / NTT_STRIDED_W, (ncols * R) << lgAo), dim3(TPB), 0,
                            c->stream, dev_lde, dev_lde, in->tw4096, lgM, in->lgB);
         GLP_HIP(hipGetLastError());
-        launch_outer<false>(c, dev_lde, dev_lde, lp->t0, lp->t1, lgAo, lgM, R, ncols * R);
+        launch_outer<false, true>(c, dev_lde, dev_lde, lp->t0, lp->t1, lgAo, lgM, R, ncols * R);
         GLP_HIP(hipGetLastError());
         return GLP_OK;
     }
@@ -750,6 +755,8 @@ int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int l
         if (np->lgA == 8)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw4096, lg,
                                np->lgB);
+        else if (np->lgA <= 4 && np->lgB >= 8)         // A <= 16 rows: register transform, no LDS
+            launch_outer<false, false>(c, dev_lde, dev_lde, nullptr, nullptr, np->lgA, np->lgB, 1, ncols * R);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw_A, lg,
                                np->lgA, np->lgB);
@@ -770,7 +777,7 @@ int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u3
     if (lg > NTT_2PASS_LG) {
         const NttPlan *in = np->inner;
         const int lgAo = np->lgAo, lgM = NTT_2PASS_LG;
-        launch_outer<true>(c, dev_values, dev_coeffs, np->it0, np->it1, lgAo, lgM, 1, ncols);
+        launch_outer<true, true>(c, dev_values, dev_coeffs, np->it0, np->it1, lgAo, lgM, 1, ncols);
         GLP_HIP(hipGetLastError());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<true>), dim3((1u << in->lgB) / NTT_STRIDED_W, ncols << lgAo), dim3(TPB), 0, c->stream,
                            dev_coeffs, dev_coeffs, in->itw4096, lgM, in->lgB);
@@ -786,6 +793,8 @@ int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u3
         if (np->lgA == 8)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs,
                                np->itw4096, lg, np->lgB);
+        else if (np->lgA <= 4 && np->lgB >= 8)
+            launch_outer<true, false>(c, dev_values, dev_coeffs, nullptr, nullptr, np->lgA, np->lgB, 1, ncols);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs, np->itw_A,
                                lg, np->lgA, np->lgB);

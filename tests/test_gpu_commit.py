@@ -37,6 +37,24 @@ def test_poseidon_parity(ctx, oracle):
         assert (got[i] == oracle.poseidon_permute(st[i])).all(), i
 
 
+def test_poseidon_parity_edge_value_soak(ctx, oracle):
+    """The device permutation keeps values non-canonical between layers and folds with hand-placed carry handling
+    (inline asm): soak it with states built from boundary values of every limb, plus a large random batch."""
+    special = np.array([0, 1, 2, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001,
+                        0xFFFFFFFEFFFFFFFF, 1 << 63, (1 << 63) - 1, 0x8000000080000000 % P, 0x00000000FFFFFFFE, 0xFFFFFFFF], dtype=np.uint64)
+    rng = np.random.default_rng(2024)
+    edge = special[rng.integers(0, len(special), size=(20000, 12))]
+    mixed = oracle.rand_field(rng, (20000, 12))
+    mask = rng.random((20000, 12)) < 0.5
+    mixed[mask] = special[rng.integers(0, len(special), size=int(mask.sum()))]
+    rnd = oracle.rand_field(rng, (100000, 12))
+    st = np.concatenate([edge, mixed, rnd])
+    got = ctx.poseidon_permute(st)
+    ref = np.stack([oracle.poseidon_permute(r) for r in st])
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, "first mismatching state %d: %s" % (bad[0], [hex(int(x)) for x in st[bad[0]]])
+
+
 @pytest.mark.parametrize("lg", [0, 1, 2, 5, 8, 11, 12, 13, 15, 16])
 def test_fft_ifft_parity(ctx, oracle, lg):
     rng = np.random.default_rng(100 + lg)

@@ -151,6 +151,25 @@ def test_unsatisfied_witness_fails_verification(ctx, oracle):
     assert (proof == ref).all()       # same (invalid) transcript on both sides
 
 
+def test_prove_parity_on_boundary_valued_wires(ctx, oracle):
+    """An (unsatisfying) witness whose wires are boundary values of the field and of its 32-bit limbs: the transcript and
+    every proof word must still equal the oracle prover's.  Exercises the lazy arithmetic of the quotient kernels
+    (non-canonical products, carry-free accumulators, base-4 limb sums) where wrap-around cases are likeliest."""
+    desc = synth.ecdsa_shape_circuit(6, seed=9)
+    special = np.array([0, 1, 2, 3, glp.P - 1, glp.P - 2, glp.P - 3, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 0xFFFFFFFF00000000,
+                        0xFFFFFFFE00000001, 0xFFFFFFFEFFFFFFFF, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF], dtype=np.uint64)
+    rng = np.random.default_rng(99)
+    w = special[rng.integers(0, len(special), size=desc.wires.shape)]
+    keep = rng.random(desc.wires.shape) < 0.3
+    w[keep] = desc.wires[keep]
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    rc, ref = oc.prove(wires=w)
+    got = gc.prove(wires=w)
+    assert (got == ref).all(), "first mismatch at word %d" % int(np.argmax(got != ref))
+    assert not gc.verify(got) and oc.verify(got) != 0
+
+
 def test_prove_properties_2_16(ctx, oracle):
     """2^16 rows x 136 wires: too slow for the oracle PROVER in a test, so check through the oracle
     VERIFIER (the relation the reference's tests assert) plus determinism."""

@@ -151,11 +151,13 @@ def test_unsatisfied_witness_fails_verification(ctx, oracle):
     assert (proof == ref).all()       # same (invalid) transcript on both sides
 
 
-def test_prove_parity_on_boundary_valued_wires(ctx, oracle):
+@pytest.mark.parametrize("which", ["ecdsa", "keccak", "zkdsa", "poseidon_chain"])
+def test_prove_parity_on_boundary_valued_wires(ctx, oracle, which):
     """An (unsatisfying) witness whose wires are boundary values of the field and of its 32-bit limbs: the transcript and
     every proof word must still equal the oracle prover's.  Exercises the lazy arithmetic of the quotient kernels
     (non-canonical products, carry-free accumulators, base-4 limb sums) where wrap-around cases are likeliest."""
-    desc = synth.ecdsa_shape_circuit(6, seed=9)
+    desc = {"ecdsa": lambda: synth.ecdsa_shape_circuit(6, seed=9), "keccak": lambda: synth.keccak_shape_circuit(6, seed=9),
+            "zkdsa": lambda: synth.zkdsa_circuit(3), "poseidon_chain": lambda: synth.poseidon_chain_circuit(5)}[which]()
     special = np.array([0, 1, 2, 3, glp.P - 1, glp.P - 2, glp.P - 3, (1 << 32) - 1, 1 << 32, (1 << 32) + 1, 0xFFFFFFFF00000000,
                         0xFFFFFFFE00000001, 0xFFFFFFFEFFFFFFFF, 1 << 63, (1 << 63) - 1, 0xFFFFFFFF], dtype=np.uint64)
     rng = np.random.default_rng(99)

@@ -100,6 +100,9 @@ def _selector_groups(gates, max_degree):
         size = 0
         while start + size < num_gates and size + gates[start + size][0] < max_degree:
             size += 1
+        if size == 0:
+            raise ValueError("gate of degree %d does not fit max_quotient_degree_factor %d (plonky2 panics here too)"
+                             % (gates[start][0], max_degree - 1))
         groups.append((start, start + size))
         start += size
     sel = []

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign (a tool, not collected by pytest): random CircuitConfig / FriConfig fields, trace sizes,
+gate mixes and public inputs; for each case the HIP library's proof must equal the CPU oracle's word for word, both
+verifiers must accept it and reject a tampered copy.  Usage: python tests/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import plonky2_lib_amd as glp
+import plonky2_lib_amd.synth as synth
+from oracle import oracle
+
+
+def random_case(rng):
+    rate_bits = int(rng.choice([1, 2, 3, 3, 3, 4]))
+    qdf = int(rng.choice([q for q in (4, 8, 16) if q <= (1 << rate_bits)] or [1 << rate_bits]))
+    if qdf < 4:
+        rate_bits, qdf = 2, 4                      # the gate set has degree-4 range products
+    lg = int(rng.integers(5, 12))
+    kw = dict(num_challenges=int(rng.choice([1, 2, 2, 2, 3, 4])), max_quotient_degree_factor=qdf, rate_bits=rate_bits,
+              cap_height=int(rng.integers(0, min(6, lg + rate_bits) + 1)), proof_of_work_bits=int(rng.choice([0, 1, 8, 16, 18])),
+              num_query_rounds=int(rng.integers(1, 30)), arity_bits=int(rng.integers(1, 5)), final_poly_bits=int(rng.integers(0, 6)))
+    wide = bool(rng.random() < 0.7)
+    config = synth.Config(136 if wide else 135, 80, **kw)
+    if sum(config.reduction_arity_bits(lg)) > lg:      # plonky2 asserts degree_bits >= arity_bits in every reduction
+        return random_case(rng)
+    npi = int(rng.choice([0, 0, 1, 3, 8, 13]))
+    pi = [int(x) for x in oracle.rand_field(rng, (npi,))]
+    gate_rows, subset = 0, None
+    if wide and lg >= 7 and qdf >= 8 and rng.random() < 0.6:     # the u32 / comparison gates need quotient degree factor 8
+        gate_rows = int(rng.integers(1, 3))
+    desc = synth.arith_circuit(lg, config, seed=int(rng.integers(1, 1 << 30)), public_inputs=pi,
+                               pi_hash=oracle.hash_no_pad(pi) if npi else None, ecdsa_gate_rows=gate_rows, ecdsa_gate_subset=subset)
+    return desc, dict(lg=lg, wide=wide, npi=npi, gate_rows=gate_rows, **kw)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    rng = np.random.default_rng(seed)
+    oracle.build()
+    ctx = glp.Context(0)
+    t0 = time.time()
+    for i in range(cases):
+        desc, info = random_case(rng)
+        oc = oracle.OracleCircuit(desc)
+        gc = glp.Circuit(ctx, desc)
+        rc, ref = oc.prove()
+        got = gc.prove()
+        ok = rc == 0 and (got == ref).all() and oc.verify(got) == 0 and gc.verify(got)
+        bad = got.copy()
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] = (int(bad[pos]) + 1) % glp.P
+        ok = ok and (not gc.verify(bad)) and oc.verify(bad) != 0
+        print("case %3d %s  %s  (%.0f s)" % (i, "ok  " if ok else "FAIL", info, time.time() - t0), flush=True)
+        if not ok:
+            if rc == 0 and not (got == ref).all():
+                print("   first differing proof word:", int(np.argmax(got != ref)), "of", len(got))
+            sys.exit(1)
+        gc.free()
+    ctx.close()
+    print("fuzz ok: %d cases, seed %d" % (cases, seed))
+
+
+if __name__ == "__main__":
+    main()

@@ -38,7 +38,7 @@ extern "C" {
 #define GLP_ERR_HIP (-2)         /* a HIP runtime call failed; message has the HIP error string */
 #define GLP_ERR_UNSUPPORTED (-3) /* valid request outside what this build implements */
 #define GLP_ERR_NOGPU (-4)       /* no gfx950 device visible */
-#define GLP_ERR_PROVE (-5)       /* the witness does not satisfy the circuit (quotient not a polynomial) */
+#define GLP_ERR_PROVE (-5)       /* prove: the transcript cannot continue (PoW search exhausted, zeta in the subgroup); verify: proof rejected */
 
 typedef struct glp_ctx glp_ctx;
 typedef struct glp_batch glp_batch; /* plonky2 `PolynomialBatch`: coefficients + LDE + Merkle tree, device resident */

@@ -50,16 +50,20 @@ __global__ __launch_bounds__(256, 4) void k_leaf_hash_lde(const u64 *__restrict_
     if (ncols <= 4) {
         for (u32 c = 0; c < ncols; c++) s[c] = p[(size_t)c * N];
     } else {
-        u32 c = 0;
-        for (; c + 8 <= ncols; c += 8) {
+        // the next eight columns are requested before the current permutation starts (the sponge overwrites s[0..8)
+        // with them afterwards), so their HBM latency hides under ~25k VALU instructions
+        u64 nx[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) s[i] = p[(size_t)(c + i) * N];
-            pos::permute(s);
-        }
-        if (c < ncols) {
+        for (int i = 0; i < 8; i++) nx[i] = i < (int)ncols ? p[(size_t)i * N] : 0;
+        for (u32 c = 0; c < ncols; c += 8) {
 #pragma unroll
             for (int i = 0; i < 8; i++)
-                if (c + i < ncols) s[i] = p[(size_t)(c + i) * N];
+                if (c + i < ncols) s[i] = nx[i];
+            if (c + 8 < ncols) {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (c + 8 + i < ncols) nx[i] = p[(size_t)(c + 8 + i) * N];
+            }
             pos::permute(s);
         }
     }

@@ -714,6 +714,66 @@ __global__ __launch_bounds__(TPB) void k_strided16(const u64 *__restrict__ in, u
     }
 }
 
+// Strided pass for A = 16 E, E = 2^EL in {2, 4, 8} (traces of 2^17 .. 2^19 rows): one radix-16 step on registers, an LDS
+// exchange with the twiddle w_A^(kb qa), then E-point transforms on registers (all remaining twiddles are powers of w_16).
+// Tile = A rows x Wc columns, Wc = 256 / E (4096 elements, 16 per thread).
+//  DIT (forward): row pb = 16 rb + ra holds k1 = E ka + kb (ra = bitrev4(ka), rb = bitrev_EL(kb)); out row q1 = qa + 16 qb.
+//  DIF (inverse): row i1 = E ia + ib natural in; out k1 = ka + 16 kb at row E ra + rb.
+template <bool DIF, int EL>
+__global__ __launch_bounds__(TPB) void k_strided16e(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                    const u64 *__restrict__ tw4096, int lg, int lgB) {
+    constexpr int E = 1 << EL, Wc = 256 >> EL;
+    __shared__ __attribute__((aligned(16))) u64 lds[4096];
+    const int tid = threadIdx.x, w = tid & (Wc - 1), g = tid >> (8 - EL);
+    const size_t n = (size_t)1 << lg, B = (size_t)1 << lgB;
+    const size_t base = (size_t)blockIdx.y * n + (size_t)blockIdx.x * Wc;
+    u64 x[16];
+    if (!DIF) {
+#pragma unroll
+        for (int ra = 0; ra < 16; ra++) x[ra] = in[base + (size_t)(16 * g + ra) * B + w];     // g = rb
+        dft16_dit<false>(x);                                                                  // over ka -> qa
+        const int kb = (int)(__brev((unsigned)g) >> (32 - EL));
+#pragma unroll
+        for (int qa = 0; qa < 16; qa++) lds[(qa * E + g) * Wc + w] = qa == 0 ? x[0] : mul_c(x[qa], tw4096[Wc * kb * qa]);
+    } else {
+#pragma unroll
+        for (int ia = 0; ia < 16; ia++) x[ia] = in[base + (size_t)(E * ia + g) * B + w];      // g = ib
+        dft16_dif<true>(x);                                                                   // over ia -> ka at x[ra]
+#pragma unroll
+        for (int ra = 0; ra < 16; ra++) {
+            const int ka = brev4(ra);
+            lds[(ra * E + g) * Wc + w] = ka == 0 ? x[ra] : mul_c(x[ra], tw4096[Wc * g * ka]);  // itw table passed in
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16 / E; j++) {
+        const int id = j * TPB + tid, w2 = id & (Wc - 1), a16 = id >> (8 - EL);                 // a16 = qa (DIT) / ra (DIF)
+        u64 y[E];
+#pragma unroll
+        for (int gg = 0; gg < E; gg++) y[gg] = lds[(a16 * E + gg) * Wc + w2];
+        if (!DIF) {
+            dft_small_dit<false, EL>(y);                                                       // over kb -> qb
+#pragma unroll
+            for (int qb = 0; qb < E; qb++) out[base + (size_t)(a16 + 16 * qb) * B + w2] = y[qb];
+        } else {
+            dft_small_dif<true, EL>(y);                                                        // over ib -> kb at y[rb]
+#pragma unroll
+            for (int rb = 0; rb < E; rb++) out[base + (size_t)(E * a16 + rb) * B + w2] = y[rb];
+        }
+    }
+}
+template <bool DIF>
+static void launch_strided16e(glp_ctx *c, const u64 *in, u64 *out, const u64 *tw, int lg, int lgA, int lgB, u32 planes) {
+    const int el = lgA - 4;
+    const dim3 g((unsigned)(((size_t)1 << lgB) / (256u >> el)), planes), b(TPB);
+    switch (el) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16e<DIF, 1>), g, b, 0, c->stream, in, out, tw, lg, lgB); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16e<DIF, 2>), g, b, 0, c->stream, in, out, tw, lg, lgB); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16e<DIF, 3>), g, b, 0, c->stream, in, out, tw, lg, lgB); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -757,6 +817,8 @@ int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int l
                                np->lgB);
         else if (np->lgA <= 4 && np->lgB >= 8)         // A <= 16 rows: register transform, no LDS
             launch_outer<false, false>(c, dev_lde, dev_lde, nullptr, nullptr, np->lgA, np->lgB, 1, ncols * R);
+        else if (np->lgA >= 5 && np->lgA <= 7 && np->lgB == 12)
+            launch_strided16e<false>(c, dev_lde, dev_lde, np->tw4096, lg, np->lgA, np->lgB, ncols * R);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw_A, lg,
                                np->lgA, np->lgB);
@@ -795,6 +857,8 @@ int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u3
                                np->itw4096, lg, np->lgB);
         else if (np->lgA <= 4 && np->lgB >= 8)
             launch_outer<true, false>(c, dev_values, dev_coeffs, nullptr, nullptr, np->lgA, np->lgB, 1, ncols);
+        else if (np->lgA >= 5 && np->lgA <= 7 && np->lgB == 12)
+            launch_strided16e<true>(c, dev_values, dev_coeffs, np->itw4096, lg, np->lgA, np->lgB, ncols);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs, np->itw_A,
                                lg, np->lgA, np->lgB);

@@ -101,6 +101,7 @@ int glp_ctx_create(int device_id, glp_ctx **out) {
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
     GLP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    GLP_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     *out = c.release();
     return GLP_OK;
 }
@@ -113,6 +114,7 @@ void glp_ctx_destroy(glp_ctx *c) {
     free_plans(c);
     c->trim();
     for (auto &kv : c->live) (void)hipFree(kv.first);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -274,8 +276,10 @@ void batch_destroy(glp_batch *b) {
 }
 
 // dev_in: values (natural) if from_values, else coefficients in natural order.
+// host_src != nullptr (BATCH_VALUES only): the values are still in host memory; they are copied into dev_in in column
+// chunks on the copy stream while the transforms of the chunks already on the device run on the compute stream.
 int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg, int rate_bits, int cap_height,
-                glp_batch **out) {
+                glp_batch **out, const u64 *host_src) {
     GLP_REQUIRE(out, "out is null");
     *out = nullptr;
     GLP_REQUIRE(ncols > 0, "ncols must be positive");
@@ -290,6 +294,36 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
     GLP_TRY(c->alloc((void **)&b->coeffs, (size_t)ncols * n * 8));
     GLP_TRY(c->alloc((void **)&b->lde, (size_t)ncols * N * 8));
     GLP_TRY(c->alloc((void **)&b->digests, b->ndigests * 32));
+    if (input_kind == BATCH_VALUES && host_src != nullptr) {
+        const u32 nchunks = std::min<u32>(8, ncols), per = (ncols + nchunks - 1) / nchunks;
+        int rc = GLP_OK;
+        std::vector<hipEvent_t> evs;
+        for (u32 c0 = 0; c0 < ncols && rc == GLP_OK; c0 += per) {
+            const u32 cn = std::min(per, ncols - c0);
+            hipEvent_t ev = nullptr;
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) evs.push_back(ev);
+            if (e == hipSuccess) e = hipMemcpyAsync(const_cast<u64 *>(dev_in) + (size_t)c0 * n, host_src + (size_t)c0 * n, (size_t)cn * n * 8,
+                                                    hipMemcpyHostToDevice, c->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(ev, c->copy_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+            if (e != hipSuccess) { rc = set_error(GLP_ERR_HIP, "witness upload: %s", hipGetErrorString(e)); break; }
+            {
+                StageScope st(c, "intt", 16.0 * n * cn);
+                rc = intt_values_to_coeffs(c, dev_in + (size_t)c0 * n, b->coeffs + (size_t)c0 * n, cn, lg);
+            }
+            if (rc == GLP_OK) {
+                StageScope st(c, "lde", (8.0 * n + 8.0 * N) * cn);
+                rc = lde_coeffs(c, b->coeffs + (size_t)c0 * n, b->lde + (size_t)c0 * N, cn, lg, rate_bits, glf::GEN);
+            }
+        }
+        if (rc != GLP_OK || !evs.empty()) (void)hipStreamSynchronize(c->copy_stream);
+        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+        GLP_TRY(rc);
+        GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests));
+        *out = b.release();
+        return GLP_OK;
+    }
     if (input_kind == BATCH_VALUES) {
         StageScope st(c, "intt", 16.0 * n * ncols);
         GLP_TRY(intt_values_to_coeffs(c, dev_in, b->coeffs, ncols, lg));
@@ -318,9 +352,13 @@ static int batch_from_host(glp_ctx *c, const u64 *host, bool from_values, u32 nc
     void *d = nullptr;
     GLP_TRY(c->alloc(&d, tot * 8));
     int rc = GLP_OK;
-    hipError_t e = hipMemcpyAsync(d, host, tot * 8, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
-    if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, from_values ? BATCH_VALUES : BATCH_COEFFS_NATURAL, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+    if (from_values) {       // upload pipelined with the transforms
+        rc = batch_build(c, (const u64 *)d, BATCH_VALUES, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out, host);
+    } else {
+        hipError_t e = hipMemcpyAsync(d, host, tot * 8, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
+        if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, BATCH_COEFFS_NATURAL, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+    }
     (void)hipStreamSynchronize(c->stream);
     c->release(d);
     return rc;

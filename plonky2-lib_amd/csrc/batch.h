@@ -15,6 +15,6 @@ struct glp_batch {
 namespace glp {
 enum BatchInput { BATCH_VALUES = 0, BATCH_COEFFS_NATURAL = 1, BATCH_COEFFS_BITREV = 2 };
 int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg, int rate_bits, int cap_height,
-                glp_batch **out);
+                glp_batch **out, const u64 *host_src = nullptr);
 void batch_destroy(glp_batch *b);
 }  // namespace glp

@@ -47,6 +47,7 @@ struct Stage {
 struct glp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // host->device witness chunks, overlapped with the transforms of earlier chunks
     int num_cus = 256;
     // size-keyed free lists: commit buffers are GB-sized and recur with identical sizes every proof
     std::multimap<size_t, void *> pool;

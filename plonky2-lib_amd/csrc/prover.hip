@@ -914,13 +914,15 @@ struct glp_session {
     u64 *proof() { return proof_words.data(); }
 
     // K1-K4 over the witness; wires cap -> proof, cap
-    int begin(const u64 *wires_dev, const u64 *public_inputs) {
+    // host_wires != nullptr: the witness is still in host memory and is uploaded into wires_dev chunk by chunk, overlapped
+    // with the iNTT / LDE of the chunks already there
+    int begin(const u64 *wires_dev, const u64 *public_inputs, const u64 *host_wires = nullptr) {
         GLP_REQUIRE(stage == S_NEW, "session already begun");
         proof_words.assign(L.total, 0);
         dev_wires = wires_dev;
         host_hash_no_pad(public_inputs, d.num_public_inputs, pih);
         if (d.num_public_inputs) memcpy(proof() + L.pis, public_inputs, (size_t)d.num_public_inputs * 8);
-        GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b));
+        GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b, host_wires));
         GLP_TRY(batch_cap_host(c, wb.b, cap));
         memcpy(proof() + L.caps, cap.data(), capn * 32);
         stage = S_WIRES;
@@ -1255,12 +1257,13 @@ static int pow_search(glp_ctx *c, const u64 st[12], const u64 *pending, u32 npen
 }
 
 // prove(): the session driven by the library's own transcript (plonk/prover.rs order)
-static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, const u64 *public_inputs, u64 *proof) {
+static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, const u64 *public_inputs, u64 *proof,
+                      const u64 *host_wires = nullptr) {
     glp_session s(c, cc);
     const glp_circuit_desc &d = cc->d;
     const Layout &L = cc->L;
     const u32 nch = s.nch, nr = s.nr, nw = s.nw, nc = s.nc, qdf = s.qdf, npp = s.npp, capn = s.capn;
-    GLP_TRY(s.begin(dev_wires, public_inputs));
+    GLP_TRY(s.begin(dev_wires, public_inputs, host_wires));
     Challenger ch;
     ch.observe(cc->digest, 4);
     ch.observe(s.pih, 4);
@@ -1546,10 +1549,9 @@ int glp_session_begin(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, 
         void *dv = nullptr;
         GLP_TRY(c->alloc(&dv, tot * 8));
         s->owned_wires = (u64 *)dv;
-        GLP_TRY(h2d(c, dv, wires, tot * 8));
         dw = s->owned_wires;
     }
-    GLP_TRY(s->begin(dw, public_inputs));
+    GLP_TRY(s->begin(dw, public_inputs, wires_on_device ? nullptr : wires));
     memcpy(wires_cap_out, s->cap.data(), (size_t)s->capn * 32);
     memcpy(public_inputs_hash_out, s->pih, 32);
     *out = s.release();
@@ -1643,12 +1645,12 @@ int glp_prove_device(glp_ctx *c, const glp_circuit *cc, const uint64_t *dev_wire
 int glp_prove(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, const uint64_t *public_inputs, uint64_t *proof_out) {
     GLP_REQUIRE(c && cc && wires && proof_out, "null argument");
     GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");
+    GLP_REQUIRE(public_inputs || cc->d.num_public_inputs == 0, "public_inputs is null");
     GLP_TRY(bind(c));
     const size_t tot = (size_t)cc->d.num_wires << cc->d.degree_bits;
     void *dv = nullptr;
     GLP_TRY(c->alloc(&dv, tot * 8));
-    int rc = h2d(c, dv, wires, tot * 8);
-    if (rc == GLP_OK) rc = glp_prove_device(c, cc, (const u64 *)dv, public_inputs, proof_out);
+    const int rc = prove_impl(c, cc, (const u64 *)dv, public_inputs, proof_out, wires);
     (void)hipStreamSynchronize(c->stream);
     c->release(dv);
     return rc;

@@ -10,7 +10,11 @@ class Group:
         self.rank, self.local_rank, self.world, self.dist, self.device = rank, local_rank, world, dist, device
 
     def barrier(self):
-        if self.dist is not None:
+        if self.dist is None:
+            return
+        if self.device is not None:            # nccl: name the device, or the barrier picks one by rank and may warn / stall
+            self.dist.barrier(device_ids=[self.device.index])
+        else:
             self.dist.barrier()
 
     def max_over_ranks(self, x):

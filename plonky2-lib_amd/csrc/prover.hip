@@ -672,12 +672,23 @@ __global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *
     __shared__ u64 sa[256], sb[256];
     const size_t n = (size_t)1 << lg;
     const u32 col = blockIdx.y, t = threadIdx.x;
+    // n / (OPEN_BLOCKS * 256) <= 2^11 terms per thread, flushed every ACC_MAX_TERMS: carry-free limb accumulators
+    // (one reduction per flush instead of a modular multiply-add per coefficient)
     u64 a = 0, b = 0;
+    AccLimb xa, xb;
+    acc2_zero(xa); acc2_zero(xb);
+    u32 terms = 0;
     for (size_t p = (size_t)blockIdx.x * 256 + t; p < n; p += (size_t)OPEN_BLOCKS * 256) {
         const u64 c = coeffs[(size_t)col * n + p];
-        a = add(a, mul(c, zt[2 * p]));
-        b = add(b, mul(c, zt[2 * p + 1]));
+        const u32 c0 = (u32)c & 0x3FFFFFu, c1 = (u32)(c >> 22) & 0x3FFFFFu, c2 = (u32)(c >> 44);
+        acc2_fma(xa, c0, c1, c2, zt[2 * p]);
+        acc2_fma(xb, c0, c1, c2, zt[2 * p + 1]);
+        if (++terms == ACC_MAX_TERMS) {
+            a = add(a, acc2_reduce(xa)); b = add(b, acc2_reduce(xb));
+            acc2_zero(xa); acc2_zero(xb); terms = 0;
+        }
     }
+    a = add(a, acc2_reduce(xa)); b = add(b, acc2_reduce(xb));
     sa[t] = a; sb[t] = b;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (t < s) { sa[t] = add(sa[t], sa[t + s]); sb[t] = add(sb[t], sb[t + s]); } __syncthreads(); }
@@ -698,20 +709,30 @@ __global__ __launch_bounds__(256) void k_final_values(FVArgs a) {
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
+    // sum_j alpha^j f_j(x): the base-field value is cut into 22-bit limbs once and multiplied into carry-free
+    // accumulators for the two extension coordinates (flushed every ACC_MAX_TERMS columns)
     ext2 acc0 = e_from(0), acc1 = e_from(0);
-    u32 j = 0;
+    AccLimb xa, xb;
+    acc2_zero(xa); acc2_zero(xb);
+    u32 j = 0, terms = 0;
     for (int k = 0; k < 4; k++) {
         const u64 *l = a.lde[k] + q;
         for (u32 c = 0; c < a.ncols[k]; c++, j++) {
             const u64 v = l[(size_t)c * N];
-            const ext2 ap = e_make(a.apow[2 * j], a.apow[2 * j + 1]);
-            acc0 = e_add(acc0, e_scale(ap, v));
+            const u32 v0 = (u32)v & 0x3FFFFFu, v1 = (u32)(v >> 22) & 0x3FFFFFu, v2 = (u32)(v >> 44);
+            acc2_fma(xa, v0, v1, v2, a.apow[2 * j]);
+            acc2_fma(xb, v0, v1, v2, a.apow[2 * j + 1]);
+            if (++terms == ACC_MAX_TERMS) {
+                acc0 = e_add(acc0, e_make(acc2_reduce(xa), acc2_reduce(xb)));
+                acc2_zero(xa); acc2_zero(xb); terms = 0;
+            }
             if (k == 2 && c < a.nch) {
                 const ext2 ap1 = e_make(a.apow[2 * c], a.apow[2 * c + 1]);
                 acc1 = e_add(acc1, e_scale(ap1, v));
             }
         }
     }
+    acc0 = e_add(acc0, e_make(acc2_reduce(xa), acc2_reduce(xb)));
     const u64 x = mul(a.g, dpow(a.w_n, q));
     const ext2 d0 = e_inv(e_sub(e_from(x), a.zeta)), d1 = e_inv(e_sub(e_from(x), a.zeta_next));
     ext2 f = e_mul(e_mul(e_sub(acc0, a.red0), d0), a.shift_acc);

@@ -19,6 +19,15 @@ def main():
     b = o.batch_from_values(vals, 3, 2)
     np.savez_compressed(os.path.join(HERE, "batch_5x32.npz"), values=vals, coeffs=b.coeffs, leaves=b.leaves,
                         digests=b.digests, cap=b.cap)
+    # one complete proof: the reference's simple-signature circuit [REF src/zkdsa/circuits/mod.rs:24-43] as rebuilt by
+    # plonky2_lib_amd.synth.zkdsa_circuit (seeded), proved by the oracle prover
+    import plonky2_lib_amd.synth as synth
+    desc = synth.zkdsa_circuit(3)
+    oc = o.OracleCircuit(desc)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    np.savez_compressed(os.path.join(HERE, "proof_zkdsa_2_3.npz"), proof=proof, circuit_digest=np.asarray(desc.circuit_digest, np.uint64),
+                        constants_sigmas_cap=oc.cs_cap, public_inputs=np.asarray(desc.public_inputs, np.uint64))
 
 
 if __name__ == "__main__":

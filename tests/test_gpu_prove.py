@@ -299,6 +299,19 @@ def test_stepped_session_equals_prove(ctx, oracle, lg, cfg):
     assert oc.verify(got) == 0
 
 
+def test_golden_proof_fixture(ctx):
+    """The committed zkdsa proof (tests/golden/proof_zkdsa_2_3.npz) is reproduced word for word by the HIP prover and
+    accepted by glp_verify -- no oracle in the loop."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "proof_zkdsa_2_3.npz"))
+    desc = synth.zkdsa_circuit(3)
+    gc = glp.Circuit(ctx, desc)
+    assert (gc.digest() == g["circuit_digest"]).all()
+    assert (gc.constants_sigmas_cap() == g["constants_sigmas_cap"]).all()
+    assert (gc.prove() == g["proof"]).all()
+    assert gc.verify(g["proof"])
+
+
 def test_verifier_rejects_tampered_proofs(ctx, oracle):
     """glp_verify (host-side restatement of plonk/verifier.rs + fri/verifier.rs, independent of the oracle) must reject a
     proof with any single word changed, section by section, and agree with the oracle's verifier on each."""

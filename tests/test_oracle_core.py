@@ -119,3 +119,20 @@ def test_oracle_matches_committed_golden_fixture(oracle):
     b = oracle.batch_from_values(g["values"], 3, 2)
     assert (b.coeffs == g["coeffs"]).all() and (b.leaves == g["leaves"]).all()
     assert (b.digests == g["digests"]).all() and (b.cap == g["cap"]).all()
+
+
+def test_oracle_prover_matches_committed_golden_proof(oracle):
+    """tests/golden/proof_zkdsa_2_3.npz (made by tests/golden/make_golden.py): every word of the zkdsa proof, the circuit
+    digest and the constants/sigmas cap must be reproduced by today's oracle."""
+    import os
+    import plonky2_lib_amd.synth as synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "proof_zkdsa_2_3.npz"))
+    desc = synth.zkdsa_circuit(3)
+    oc = oracle.OracleCircuit(desc)
+    rc, proof = oc.prove()
+    assert rc == 0
+    assert (np.asarray(desc.circuit_digest, np.uint64) == g["circuit_digest"]).all()
+    assert (oc.cs_cap == g["constants_sigmas_cap"]).all()
+    assert (np.asarray(desc.public_inputs, np.uint64) == g["public_inputs"]).all()
+    assert (proof == g["proof"]).all()
+    assert oc.verify(g["proof"]) == 0

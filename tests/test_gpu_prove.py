@@ -74,6 +74,12 @@ def test_prove_parity_config_sweep(ctx, oracle, kw):
     _check(ctx, oracle, desc)
 
 
+def test_prove_parity_wide_ecc_config(ctx, oracle):
+    """`CircuitConfig::wide_ecc_config` (234 wires) [REF src/ecdsa/gadgets/ecdsa.rs:489]: 30 sponge permutations per wires leaf."""
+    desc = synth.arith_circuit(8, synth.Config(234, 80), seed=52)
+    _check(ctx, oracle, desc)
+
+
 def test_prove_parity_non_geometric_coset_shifts(ctx, oracle):
     """k_is that are NOT 1, g, g^2, ... take the generic path of the permutation kernel (the chained multiply-by-g
     shortcut only applies to plonky2's own choice of shifts)."""

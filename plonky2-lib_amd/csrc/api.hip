@@ -295,7 +295,8 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
     GLP_TRY(c->alloc((void **)&b->lde, (size_t)ncols * N * 8));
     GLP_TRY(c->alloc((void **)&b->digests, b->ndigests * 32));
     if (input_kind == BATCH_VALUES && host_src != nullptr) {
-        const u32 nchunks = std::min<u32>(8, ncols), per = (ncols + nchunks - 1) / nchunks;
+        // chunking pays when a chunk's copy is long against a few launches: below 64 MB the witness goes up in one piece
+        const u32 nchunks = ((size_t)ncols * n * 8 < ((size_t)64 << 20)) ? 1u : std::min<u32>(8, ncols), per = (ncols + nchunks - 1) / nchunks;
         int rc = GLP_OK;
         std::vector<hipEvent_t> evs;
         for (u32 c0 = 0; c0 < ncols && rc == GLP_OK; c0 += per) {

@@ -19,9 +19,10 @@ int merkle_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height);
 size_t merkle_cap_offset(size_t nleaves, int cap_height);
 // gather `count` leaves / proofs
 int merkle_gather_lde_rows(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, const u64 *dev_leaf_idx,
-                           u32 count, u64 *dev_out /*[count][ncols]*/);
+                           u32 count, u64 *dev_out /*[count][ncols]*/, size_t out_stride = 0 /* 0: ncols */);
 int merkle_gather_paths(glp_ctx *c, const u64 *dev_digests, size_t nleaves, int cap_height, const u64 *dev_leaf_idx,
-                        u32 count, u64 *dev_out /*[count][depth][4]*/);
+                        u32 count, u64 *dev_out /*[count][depth][4]*/, size_t out_stride = 0 /* 0: 4 depth */,
+                        u32 idx_shift = 0 /* leaf = idx >> idx_shift */);
 int poseidon_permute_states(glp_ctx *c, u64 *dev_states, size_t count);
 
 }  // namespace glp

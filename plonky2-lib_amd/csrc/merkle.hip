@@ -199,8 +199,9 @@ int merkle_from_rows(glp_ctx *c, const u64 *dev_rows, size_t nleaves, u32 leaf_l
     return build_levels(c, dev_digests, nleaves, cap_height);
 }
 
+// out[k * out_stride + col]: a record stride lets the prover gather straight into the proof's query layout
 __global__ void k_gather_lde_rows(const u64 *__restrict__ lde, u32 ncols, int lg, int rate_bits,
-                                  const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out) {
+                                  const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out, size_t out_stride) {
     const size_t N = (size_t)1 << (lg + rate_bits);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)count * ncols) return;
@@ -209,39 +210,42 @@ __global__ void k_gather_lde_rows(const u64 *__restrict__ lde, u32 ncols, int lg
     // leaf j <-> point index i = bitrev_N(j) = q*R + r  <-> slot (r, q)
     const u32 rtop = (u32)(j >> lg), jl = (u32)(j & (((u64)1 << lg) - 1));
     const size_t pos = ((size_t)bitrev32(rtop, rate_bits) << lg) | bitrev32(jl, lg);
-    out[t] = lde[(size_t)col * N + pos];
+    out[(size_t)k * out_stride + col] = lde[(size_t)col * N + pos];
 }
 
+// leaf index = leaf_idx[k] >> idx_shift (FRI layer r looks at x_index >> sum of the arities so far)
 __global__ void k_gather_paths(const u64 *__restrict__ digests, size_t nleaves, int depth,
-                               const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out) {
+                               const u64 *__restrict__ leaf_idx, u32 idx_shift, u32 count, u64 *__restrict__ out, size_t out_stride) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)count * depth * 4) return;
     const u32 e = (u32)(t & 3);
     const u32 lvl = (u32)((t >> 2) % depth), k = (u32)((t >> 2) / depth);
     size_t off = 0, w = nleaves;
     for (u32 l = 0; l < lvl; l++) { off += w; w >>= 1; }
-    const size_t idx = (leaf_idx[k] >> lvl) ^ 1;
-    out[t] = digests[4 * (off + idx) + e];
+    const size_t idx = ((leaf_idx[k] >> idx_shift) >> lvl) ^ 1;
+    out[(size_t)k * out_stride + 4 * lvl + e] = digests[4 * (off + idx) + e];
 }
 
 int merkle_gather_lde_rows(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, const u64 *dev_leaf_idx,
-                           u32 count, u64 *dev_out) {
+                           u32 count, u64 *dev_out, size_t out_stride) {
+    if (out_stride == 0) out_stride = ncols;
     const size_t total = (size_t)count * ncols;
     if (!total) return GLP_OK;
     hipLaunchKernelGGL(k_gather_lde_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dev_lde, ncols, lg,
-                       rate_bits, dev_leaf_idx, count, dev_out);
+                       rate_bits, dev_leaf_idx, count, dev_out, out_stride);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }
 
 int merkle_gather_paths(glp_ctx *c, const u64 *dev_digests, size_t nleaves, int cap_height, const u64 *dev_leaf_idx,
-                        u32 count, u64 *dev_out) {
+                        u32 count, u64 *dev_out, size_t out_stride, u32 idx_shift) {
     int depth = 0;
     for (size_t w = nleaves; w > ((size_t)1 << cap_height); w >>= 1) depth++;
+    if (out_stride == 0) out_stride = (size_t)depth * 4;
     const size_t total = (size_t)count * depth * 4;
     if (!total) return GLP_OK;
     hipLaunchKernelGGL(k_gather_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dev_digests, nleaves,
-                       depth, dev_leaf_idx, count, dev_out);
+                       depth, dev_leaf_idx, idx_shift, count, dev_out, out_stride);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }

@@ -808,18 +808,19 @@ __global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ex
     newc[p] = acc.a; newc[nnew + p] = acc.b;
 }
 // leaf evals for the query phase: out[k][2*t..] = the arity values of leaf idx[k]
-__global__ void k_fri_gather_leaf(const u64 *vals, u32 lgL, u32 rb, u32 ab, const u64 *idx, u32 count, u64 *out) {
+__global__ void k_fri_gather_leaf(const u64 *vals, u32 lgL, u32 rb, u32 ab, const u64 *idx, u32 idx_shift, u32 count, u64 *out,
+                                  size_t out_stride) {
     const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
     const u32 arity = 1u << ab;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)count * arity) return;
     const u32 k = (u32)(gid / arity), t = (u32)(gid % arity);
-    const size_t m = idx[k];
+    const size_t m = idx[k] >> idx_shift;
     const size_t Mp = bitrev32((u32)m, lgL - ab);
     const size_t i = (size_t)bitrev32(t, ab) * nleaves + Mp;
     const size_t pos = (i & (((size_t)1 << rb) - 1)) * ncur + (i >> rb);
-    out[((size_t)k * arity + t) * 2] = vals[pos];
-    out[((size_t)k * arity + t) * 2 + 1] = vals[L + pos];
+    out[(size_t)k * out_stride + 2 * t] = vals[pos];
+    out[(size_t)k * out_stride + 2 * t + 1] = vals[L + pos];
 }
 
 // K10: proof-of-work grinding; smallest candidate in [base, base + count) whose response has `bits` leading zeros
@@ -868,20 +869,21 @@ int batch_cap_host(glp_ctx *c, const glp_batch *b, std::vector<u64> &cap) {
     cap.resize((size_t)4 << b->cap_height);
     return d2h(c, cap.data(), b->digests + 4 * merkle_cap_offset(N, b->cap_height), cap.size() * 8);
 }
-// evaluate every polynomial of a batch at z: out[col] (ext)
-int open_batch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial, std::vector<ext2> &out) {
+// evaluate every polynomial of a batch at z: launch only; partial sums land in dev_partial [ncols][OPEN_BLOCKS][2]
+int open_batch_launch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial) {
     dim3 g(OPEN_BLOCKS, b->ncols);
     hipLaunchKernelGGL(k_open_dot, g, dim3(256), 0, c->stream, b->coeffs, dev_zt, dev_partial, (u32)b->lg);
     GLP_HIP(hipGetLastError());
-    std::vector<u64> h((size_t)b->ncols * OPEN_BLOCKS * 2);
-    GLP_TRY(d2h(c, h.data(), dev_partial, h.size() * 8));
-    out.resize(b->ncols);
-    for (u32 col = 0; col < b->ncols; col++) {
+    return GLP_OK;
+}
+// host side of the same: fold the OPEN_BLOCKS partial sums of each column
+void open_batch_finish(const u64 *h, u32 ncols, std::vector<ext2> &out) {
+    out.resize(ncols);
+    for (u32 col = 0; col < ncols; col++) {
         u64 a = 0, bb = 0;
         for (int k = 0; k < OPEN_BLOCKS; k++) { a = add(a, h[2 * ((size_t)col * OPEN_BLOCKS + k)]); bb = add(bb, h[2 * ((size_t)col * OPEN_BLOCKS + k) + 1]); }
         out[col] = e_make(a, bb);
     }
-    return GLP_OK;
 }
 int zeta_table(glp_ctx *c, ext2 z, int lg, u64 *dev_zt) {
     ZTArgs za;
@@ -1076,16 +1078,21 @@ struct glp_session {
         ob[0] = cc->cs; ob[1] = wb.b; ob[2] = zb.b; ob[3] = qb.b;
         {
         StageScope st(c, "openings", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3] + nzp));
+        // five evaluations (four batches at zeta, the Z batch at g zeta) queued back to back, one copy back
         u64 *zt, *partial;
         GLP_TRY(tmp.get(&zt, 2 * n));
-        u32 maxc = 0;
-        for (int k = 0; k < 4; k++) maxc = std::max(maxc, ob[k]->ncols);
-        GLP_TRY(tmp.get(&partial, (size_t)maxc * OPEN_BLOCKS * 2));
+        size_t poff[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 5; k++) poff[k + 1] = poff[k] + (size_t)(k < 4 ? ob[k] : zb.b)->ncols * OPEN_BLOCKS * 2;
+        GLP_TRY(tmp.get(&partial, poff[5]));
         GLP_TRY(zeta_table(c, zeta, lg, zt));
-        for (int k = 0; k < 4; k++) GLP_TRY(open_batch(c, ob[k], zt, partial, open[k]));
+        for (int k = 0; k < 4; k++) GLP_TRY(open_batch_launch(c, ob[k], zt, partial + poff[k]));
         GLP_TRY(zeta_table(c, zeta_next, lg, zt));
+        GLP_TRY(open_batch_launch(c, zb.b, zt, partial + poff[4]));
+        std::vector<u64> hp(poff[5]);
+        GLP_TRY(d2h(c, hp.data(), partial, hp.size() * 8));
+        for (int k = 0; k < 4; k++) open_batch_finish(hp.data() + poff[k], ob[k]->ncols, open[k]);
         std::vector<ext2> all;
-        GLP_TRY(open_batch(c, zb.b, zt, partial, all));
+        open_batch_finish(hp.data() + poff[4], zb.b->ncols, all);
         zs_next.assign(all.begin(), all.begin() + nch);
     }
         {
@@ -1206,43 +1213,35 @@ struct glp_session {
         StageScope st(c, "fri_queries", 0.0);
         std::vector<u64> xi(indices, indices + nq);
         for (u32 q = 0; q < nq; q++) GLP_REQUIRE(xi[q] < (u64)N, "query index %llu outside the LDE domain", (unsigned long long)xi[q]);
-        u64 *dev_idx, *dev_buf;
+        // every gather writes straight into a device image of the proof's query section; one copy brings it back
+        u64 *dev_idx, *dev_q;
+        const size_t stride = L.query_stride;
         GLP_TRY(tmp.get(&dev_idx, nq));
-        size_t maxbuf = 0;
-        for (int k = 0; k < 4; k++) maxbuf = std::max(maxbuf, (size_t)nq * std::max<size_t>(ob[k]->ncols, 4 * (size_t)L.depth0));
-        for (auto &ly : layers) maxbuf = std::max(maxbuf, (size_t)nq * std::max<size_t>((size_t)2 << ly.ab, 4 * (size_t)(ly.lgL - ly.ab)));
-        GLP_TRY(tmp.get(&dev_buf, maxbuf + 8));
-        std::vector<u64> h(maxbuf + 8);
+        GLP_TRY(tmp.get(&dev_q, (size_t)nq * stride));
         GLP_TRY(h2d(c, dev_idx, xi.data(), nq * 8));
         size_t off = 0;   // word offset inside one query record
         for (int k = 0; k < 4; k++) {
             const u32 ncol = ob[k]->ncols;
-            GLP_TRY(merkle_gather_lde_rows(c, ob[k]->lde, ncol, lg, rb, dev_idx, nq, dev_buf));
-            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * ncol * 8));
-            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * ncol, (size_t)ncol * 8);
+            GLP_TRY(merkle_gather_lde_rows(c, ob[k]->lde, ncol, lg, rb, dev_idx, nq, dev_q + off, stride));
             off += ncol;
-            GLP_TRY(merkle_gather_paths(c, ob[k]->digests, N, (int)d.cap_height, dev_idx, nq, dev_buf));
-            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * L.depth0 * 32));
-            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * L.depth0 * 4, (size_t)L.depth0 * 32);
+            GLP_TRY(merkle_gather_paths(c, ob[k]->digests, N, (int)d.cap_height, dev_idx, nq, dev_q + off, stride, 0));
             off += 4 * (size_t)L.depth0;
         }
+        u32 shift_bits = 0;
         for (size_t r = 0; r < layers.size(); r++) {
             const Layer &ly = layers[r];
-            const u32 arity = 1u << ly.ab, depth = L.step_depth[r];
+            const u32 arity = 1u << ly.ab;
             const size_t nleaves = ((size_t)1 << ly.lgL) >> ly.ab;
-            for (u32 q = 0; q < nq; q++) xi[q] >>= ly.ab;
-            GLP_TRY(h2d(c, dev_idx, xi.data(), nq * 8));
+            shift_bits += ly.ab;
             hipLaunchKernelGGL(k_fri_gather_leaf, dim3(nblk((size_t)nq * arity)), dim3(256), 0, c->stream, ly.vals, ly.lgL, (u32)rb,
-                               ly.ab, dev_idx, nq, dev_buf);
+                               ly.ab, dev_idx, shift_bits, nq, dev_q + off, stride);
             GLP_HIP(hipGetLastError());
-            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * arity * 16));
-            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * arity * 2, (size_t)arity * 16);
             off += 2 * (size_t)arity;
-            GLP_TRY(merkle_gather_paths(c, ly.dig, nleaves, (int)d.cap_height, dev_idx, nq, dev_buf));
-            GLP_TRY(d2h(c, h.data(), dev_buf, (size_t)nq * depth * 32));
-            for (u32 q = 0; q < nq; q++) memcpy(proof() + L.queries + (size_t)q * L.query_stride + off, h.data() + (size_t)q * depth * 4, (size_t)depth * 32);
-            off += 4 * (size_t)depth;
+            GLP_TRY(merkle_gather_paths(c, ly.dig, nleaves, (int)d.cap_height, dev_idx, nq, dev_q + off, stride, shift_bits));
+            off += 4 * (size_t)L.step_depth[r];
         }
+        if (off != stride) return set_error(GLP_ERR_ARG, "internal: query record layout mismatch");
+        GLP_TRY(d2h(c, proof() + L.queries, dev_q, (size_t)nq * stride * 8));
         stage = S_DONE;
         return GLP_OK;
     }

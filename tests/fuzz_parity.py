@@ -32,9 +32,22 @@ def random_case(rng):
     gate_rows, subset = 0, None
     if wide and lg >= 7 and qdf >= 8 and rng.random() < 0.6:     # the u32 / comparison gates need quotient degree factor 8
         gate_rows = int(rng.integers(1, 3))
-    desc = synth.arith_circuit(lg, config, seed=int(rng.integers(1, 1 << 30)), public_inputs=pi,
-                               pi_hash=oracle.hash_no_pad(pi) if npi else None, ecdsa_gate_rows=gate_rows, ecdsa_gate_subset=subset)
-    return desc, dict(lg=lg, wide=wide, npi=npi, gate_rows=gate_rows, **kw)
+    family = "arith"
+    seed = int(rng.integers(1, 1 << 30))
+    if qdf >= 8 and rng.random() < 0.75:       # PoseidonGate (degree 7) and the reference's u32 gates need quotient degree factor 8
+        family = str(rng.choice(["poseidon_chain", "u32", "zkdsa", "keccak"]))
+    if family == "poseidon_chain":
+        desc = synth.poseidon_chain_circuit(max(lg, 5), config, seed=seed)
+    elif family == "u32":
+        desc = synth.u32_circuit(max(lg, 6), config, seed=seed)
+    elif family == "zkdsa":
+        desc = synth.zkdsa_circuit(3, config, seed=seed)
+    elif family == "keccak":
+        desc = synth.keccak_shape_circuit(max(lg, 6), seed=seed)
+    else:
+        desc = synth.arith_circuit(lg, config, seed=seed, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi) if npi else None,
+                                   ecdsa_gate_rows=gate_rows, ecdsa_gate_subset=subset)
+    return desc, dict(family=family, lg=int(desc.degree_bits), wide=wide, npi=len(desc.public_inputs), gate_rows=gate_rows, **kw)
 
 
 def main():

@@ -294,6 +294,9 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
+                "kernel_symbol": {"merkle_leaves": "glp::k_leaf_hash_lde", "lde": "glp::k_lde_contig16 + glp::k_strided16<false>",
+                                  "quotient_eval": "k_quotient<2,false> + k_quotient_gate<2,T>"}.get(dom.split("/")[-1]),
+                "launch_ms": stage_out[dom]["ms"],
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign (a tool, not collected by pytest): random CircuitConfig / FriConfig fields, trace sizes,
 gate mixes and public inputs; for each case the HIP library's proof must equal the CPU oracle's word for word, both
-verifiers must accept it and reject a tampered copy.  Usage: python tests/fuzz_parity.py [cases] [seed]"""
+verifiers must accept it and reject a tampered copy.  Usage: python tests/fuzz_parity.py [cases] [seed]   (FUZZ_MIN_LG / FUZZ_MAX_LG bound the trace length, default 5..11)"""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ def random_case(rng):
     qdf = int(rng.choice([q for q in (4, 8, 16) if q <= (1 << rate_bits)] or [1 << rate_bits]))
     if qdf < 4:
         rate_bits, qdf = 2, 4                      # the gate set has degree-4 range products
-    lg = int(rng.integers(5, 12))
+    lg = int(rng.integers(int(os.environ.get("FUZZ_MIN_LG", "5")), int(os.environ.get("FUZZ_MAX_LG", "11")) + 1))
     kw = dict(num_challenges=int(rng.choice([1, 2, 2, 2, 3, 4])), max_quotient_degree_factor=qdf, rate_bits=rate_bits,
               cap_height=int(rng.integers(0, min(6, lg + rate_bits) + 1)), proof_of_work_bits=int(rng.choice([0, 1, 8, 16, 18])),
               num_query_rounds=int(rng.integers(1, 30)), arity_bits=int(rng.integers(1, 5)), final_poly_bits=int(rng.integers(0, 6)))

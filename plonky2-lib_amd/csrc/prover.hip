@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 l
 // prod_{x < bound} (v - x), v canonical -> NON-canonical u64 (it only ever feeds acc_fma, which takes any u64)
 __device__ __forceinline__ u64 range_product(u64 v, u32 bound) {
     if (bound == 4) {                       // v(v-3) * (v-1)(v-2) = u (u + 2): two multiplications instead of three
-        const u64 u = mul(v, sub(v, 3));
+        const u64 u = mul_nc(v, add_cnc(v, P - 3));       // v - 3 as v + (p - 3), left non-canonical; u any u64
         return mul_nc(u, add_cnc(2, u));
     }
     u64 p = v;

@@ -319,7 +319,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
             u32 k = 0;
             u64 st[12];
             const u64 swap = W[(size_t)24 * N];
-            EMIT(k, mul(swap, sub(swap, 1))); k++;
+            EMIT(k, mul_nc(swap, sub(swap, 1))); k++;
             for (u32 i = 0; i < 4; i++) {
                 const u64 lhs = W[(size_t)i * N], rhs = W[(size_t)(i + 4) * N], dl = W[(size_t)(25 + i) * N];
                 EMIT(k, sub(mul(swap, sub(rhs, lhs)), dl)); k++;
@@ -364,7 +364,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                     const u64 bit = bits[(size_t)b * N];
                     cx = add(dbl(cx), bit);
                     cxi = add(dbl(dbl(cxi)), bit);
-                    EMIT(kb + b, mul(bit, sub(bit, 1)));
+                    EMIT(kb + b, mul_nc(bit, sub(bit, 1)));
                 }
                 EMIT(k, sub(cx, xw));
                 EMIT(k + 1, sub(cxi, xi));
@@ -385,8 +385,8 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                     cxi = add(dbl(add(dbl(cxi), be)), bo);
                     if (g.type == GLP_GATE_UNINTERLEAVE_U32) { ce = add(dbl(ce), be); co = add(dbl(co), bo); }
                     else { ce = add(dbl(dbl(ce)), be); co = add(dbl(dbl(co)), bo); }
-                    EMIT(kb + 2 * j, mul(be, sub(be, 1)));
-                    EMIT(kb + 2 * j + 1, mul(bo, sub(bo, 1)));
+                    EMIT(kb + 2 * j, mul_nc(be, sub(be, 1)));
+                    EMIT(kb + 2 * j + 1, mul_nc(bo, sub(bo, 1)));
                 }
                 EMIT(k, sub(cxi, xi));
                 EMIT(k + 1, sub(ce, xe));
@@ -401,7 +401,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 const u64 m0 = W[(size_t)(6 * i) * N], m1 = W[(size_t)(6 * i + 1) * N], ad = W[(size_t)(6 * i + 2) * N];
                 const u64 lo = W[(size_t)(6 * i + 3) * N], hi = W[(size_t)(6 * i + 4) * N], iv = W[(size_t)(6 * i + 5) * N];
                 const u64 hi_not_max = sub(mul(iv, sub(0xFFFFFFFFull, hi)), 1);
-                EMIT(k, mul(hi_not_max, lo)); k++;
+                EMIT(k, mul_nc(hi_not_max, lo)); k++;
                 EMIT(k, sub(add(mul(hi, (u64)1 << 32), lo), add(mul(m0, m1), ad))); k++;
                 u64 cl = 0, chh = 0;
                 const u64 *limbs = W + (size_t)(6 * nops + 32 * i) * N;
@@ -440,7 +440,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 (void)unused_hi;
                 k += 16;
                 EMIT(k, sub(cl, res)); k++;
-                EMIT(k, mul(bo, sub(1, bo))); k++;
+                EMIT(k, mul_nc(bo, sub(1, bo))); k++;
             }
             break;
         }
@@ -480,7 +480,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                         EMIT(k, range_product(lb[t], cs)); k++;
                         const u64 diff = sub(lb[t], la[t]);
                         EMIT(k, sub(mul(diff, ld[t]), sub(1, le[t]))); k++;
-                        EMIT(k, mul(le[t], diff)); k++;
+                        EMIT(k, mul_nc(le[t], diff)); k++;
                         EMIT(k, sub(li[t], mul(le[t], msd))); k++;
                         msd = add(li[t], mul(sub(1, le[t]), diff));
                     }
@@ -488,7 +488,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
             const u64 msdw = W[(size_t)3 * N];
             EMIT(k, sub(msdw, msd)); k++;
             u64 bc = 0;
-            for (u32 j = 0; j <= cb; j++) { const u64 bit = mb[(size_t)j * N]; EMIT(k, mul(bit, sub(1, bit))); k++; }
+            for (u32 j = 0; j <= cb; j++) { const u64 bit = mb[(size_t)j * N]; EMIT(k, mul_nc(bit, sub(1, bit))); k++; }
             for (int j = (int)cb; j >= 0; j--) bc = add(dbl(bc), mb[(size_t)j * N]);
             EMIT(k, sub(add((u64)cs, msdw), bc)); k++;
             EMIT(k, sub(W[(size_t)2 * N], mb[(size_t)cb * N])); k++;
@@ -508,7 +508,7 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
             for (u32 cpy = 0; cpy < copies; cpy++) {
                 const u64 *bse = W + (size_t)((2 + vs) * cpy) * N, *bw = W + (size_t)(routed + bits * cpy) * N;
                 u64 idx = 0;
-                for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; EMIT(k, mul(bit, sub(bit, 1))); k++; }
+                for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; EMIT(k, mul_nc(bit, sub(bit, 1))); k++; }
                 for (int b = (int)bits - 1; b >= 0; b--) idx = add(dbl(idx), bw[(size_t)b * N]);
                 EMIT(k, sub(idx, bse[0])); k++;
                 u64 sel;

@@ -50,3 +50,26 @@ def test_product_does_not_reference_oracle():
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle/" not in txt.replace("tests/test_oracle", "") or f == "gen_poseidon_constants.py", (dp, f)
                 assert "import oracle" not in txt and "from oracle" not in txt, (dp, f)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/glp.h must be usable from C (what cgo / Rust bindgen / JNI see): csrc/examples/abi_smoke.c is compiled as C99
+    with -Wall -Werror and linked against libglprover.so.  Without a GPU it must fail loudly, not fall back."""
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(here, "plonky2-lib_amd")
+    glp.build_library()
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(here, "include"),
+                           os.path.join(pkg, "csrc", "examples", "abi_smoke.c"), "-L", pkg, "-lglprover",
+                           "-Wl,-rpath," + pkg, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stderr
+    else:
+        assert r.returncode == 2 and "glp_ctx_create" in r.stderr

@@ -53,6 +53,13 @@ GLP_API int glp_ctx_synchronize(glp_ctx *ctx);
 /* The HIP stream (hipStream_t) every kernel of this ctx is launched on. */
 GLP_API void *glp_ctx_stream(glp_ctx *ctx);
 
+/* Device buffers for the *_device entry points, for callers that do not link a HIP runtime themselves (a Rust / Go host
+ * that keeps a witness resident in HBM across proofs).  Memory comes from and returns to the context's pool. */
+GLP_API int glp_dev_alloc(glp_ctx *ctx, size_t bytes, void **dev_out);
+GLP_API int glp_dev_free(glp_ctx *ctx, void *dev);
+GLP_API int glp_dev_upload(glp_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);     /* synchronous */
+GLP_API int glp_dev_download(glp_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);   /* synchronous */
+
 /* ---- per-stage device timing (hipEvent pairs on the ctx stream) -------------------------------
  * With profiling on, each kernel stage of the following calls is bracketed by events.
  * glp_ctx_stage_count / glp_ctx_stage_get read them back after synchronising. */

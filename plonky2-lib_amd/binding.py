@@ -125,6 +125,10 @@ def load_library():
         "glp_session_proof": [vp, vp],
         "glp_session_end": [vp],
         "glp_verify": [vp, vp],
+        "glp_dev_alloc": [vp, sz, C.POINTER(vp)],
+        "glp_dev_free": [vp, vp],
+        "glp_dev_upload": [vp, vp, vp, sz],
+        "glp_dev_download": [vp, vp, vp, sz],
     })
     for name in ("glp_num_openings", "glp_final_poly_len"):
         getattr(L, name).restype = sz
@@ -234,6 +238,22 @@ class Context:
         _chk(load_library().glp_lde(self._h, _p(a), a.shape[0], int(a.shape[1]).bit_length() - 1, rate_bits, shift, _p(out)))
         return out
 
+    def dev_alloc(self, nbytes):
+        """Device buffer from the context's pool (for the *_device entry points); returns the pointer as an int."""
+        p = C.c_void_p()
+        _chk(load_library().glp_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        _chk(load_library().glp_dev_free(self._h, C.c_void_p(ptr)))
+
+    def dev_upload(self, ptr, array):
+        a = np.ascontiguousarray(array)
+        _chk(load_library().glp_dev_upload(self._h, C.c_void_p(ptr), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def dev_download(self, ptr, array):
+        _chk(load_library().glp_dev_download(self._h, array.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), array.nbytes))
+
     def fill_random_device(self, dev_ptr, count, seed):
         _chk(load_library().glp_fill_random_device(self._h, C.c_void_p(dev_ptr), count, seed))
 
@@ -278,7 +298,8 @@ class Batch:
 
     def free(self):
         if self._h:
-            load_library().glp_batch_free(self._h)
+            if getattr(self.ctx, "_h", None):                # never touch a handle whose context is already gone
+                load_library().glp_batch_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -353,7 +374,8 @@ class Circuit:
 
     def free(self):
         if getattr(self, "_h", None):
-            load_library().glp_circuit_free(self._h)
+            if getattr(self.ctx, "_h", None):                # never touch a handle whose context is already gone
+                load_library().glp_circuit_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -485,7 +507,8 @@ class Session:
 
     def end(self):
         if getattr(self, "_h", None):
-            load_library().glp_session_end(self._h)
+            if getattr(self.circuit.ctx, "_h", None):        # a session must not outlive its context: then it is only dropped
+                load_library().glp_session_end(self._h)
             self._h = None
 
     def __del__(self):

@@ -127,6 +127,35 @@ int glp_ctx_synchronize(glp_ctx *c) {
 }
 void *glp_ctx_stream(glp_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+int glp_dev_alloc(glp_ctx *c, size_t bytes, void **dev_out) {
+    GLP_REQUIRE(c && dev_out && bytes > 0, "null argument or zero size");
+    *dev_out = nullptr;
+    GLP_TRY(bind(c));
+    return c->alloc(dev_out, bytes);
+}
+int glp_dev_free(glp_ctx *c, void *dev) {
+    GLP_REQUIRE(c, "null context");
+    if (!dev) return GLP_OK;
+    GLP_TRY(bind(c));
+    GLP_REQUIRE(c->live.count(dev), "pointer was not allocated by glp_dev_alloc on this context");
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    c->release(dev);
+    return GLP_OK;
+}
+int glp_dev_upload(glp_ctx *c, void *dev_dst, const void *host_src, size_t bytes) {
+    GLP_REQUIRE(c && dev_dst && host_src, "null argument");
+    GLP_TRY(bind(c));
+    GLP_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+int glp_dev_download(glp_ctx *c, void *host_dst, const void *dev_src, size_t bytes) {
+    GLP_REQUIRE(c && host_dst && dev_src, "null argument");
+    GLP_TRY(bind(c));
+    GLP_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
 int glp_ctx_set_profiling(glp_ctx *c, int on) {
     GLP_REQUIRE(c, "null ctx");
     c->profiling = on != 0;

@@ -351,6 +351,60 @@ def test_verifier_rejects_unsatisfied_witness(ctx, oracle):
     assert gc.verify(gc.prove())
 
 
+def test_stepped_session_with_device_resident_wires(ctx, oracle):
+    """glp_session_begin(wires_on_device = 1): the witness already sits in HBM (what bench.py times through
+    glp_prove_device); same proof as from host wires."""
+    desc = synth.ecdsa_shape_circuit(7, seed=21)
+    gc = glp.Circuit(ctx, desc)
+    ref = gc.prove()
+    w = np.ascontiguousarray(desc.wires)
+    dptr = ctx.dev_alloc(w.nbytes)                           # glp_dev_alloc / glp_dev_upload: no HIP runtime on the caller's side
+    ctx.dev_upload(dptr, w)
+    back = np.empty_like(w)
+    ctx.dev_download(dptr, back)
+    assert (back == w).all()
+    assert (gc.prove_device(dptr) == ref).all()
+    s = glp.Session(gc, dev_wires_ptr=dptr)
+    ch = oracle.Challenger()
+    ch.observe(gc.digest())
+    ch.observe(s.public_inputs_hash)
+    ch.observe(s.wires_cap)
+    nch = desc.num_challenges
+    betas, gammas = ch.get_n(nch), ch.get_n(nch)
+    zs_cap = s.partial_products(betas, gammas)
+    cap = 4 << desc.cap_height
+    assert (s.wires_cap.reshape(-1) == ref[:cap]).all() and (zs_cap.reshape(-1) == ref[cap:2 * cap]).all()
+    s.end()
+    ctx.dev_free(dptr)
+    with pytest.raises(glp.GlpError):
+        ctx.dev_free(dptr)                                   # not (any longer) a live allocation of this context
+
+
+def test_pow_search_is_the_smallest_witness(ctx, oracle):
+    """glp_pow_search on an arbitrary sponge state: the returned witness satisfies the leading-zero condition under the oracle's
+    transcript and no smaller one does."""
+    import ctypes
+    desc = synth.arith_circuit(5, synth.Config.standard_recursion_config(), seed=8)
+    gc = glp.Circuit(ctx, desc)
+    s = glp.Session(gc)
+    ch = oracle.Challenger()
+    ch.observe(np.arange(1, 12, dtype=np.uint64))            # 11 elements: one duplex, three pending inputs
+    raw = np.frombuffer(ctypes.string_at(ch._buf, 8 * 21), dtype=np.uint64)
+    nin = int(np.frombuffer(ctypes.string_at(ctypes.addressof(ch._buf) + 8 * 20, 4), dtype=np.int32)[0])
+    assert nin == 3
+    bits = 10
+    w = s.pow_search(raw[:12], raw[12:12 + nin], bits)
+    s.end()
+
+    def response(cand):
+        c2 = oracle.Challenger()
+        ctypes.memmove(c2._buf, ch._buf, len(ch._buf))
+        c2.observe([cand])
+        return c2.get()
+    assert response(w) >> (64 - bits) == 0
+    assert all(response(c) >> (64 - bits) != 0 for c in range(w))
+
+
 def test_stepped_session_enforces_order(ctx):
     desc = synth.arith_circuit(5, synth.Config.standard_recursion_config(), seed=3)
     gc = glp.Circuit(ctx, desc)

@@ -9,7 +9,9 @@ here (no Rust, plonky2 fork absent), so the trace is synthetic: SplitMix64-seede
 elements of exactly that shape, generated directly in HBM.
 
 One "step" = one complete prove() (everything after witness generation) from an HBM-resident witness.
-Usage: python bench.py --gpus N --steps K --warmup W     (N>1: launched by torch.distributed.run)
+Usage: python bench.py --gpus N --steps K --warmup W
+  N > 1 under torch.distributed.run (RANK / WORLD_SIZE set): this process is one rank.
+  N > 1 started bare: bench.py starts the N ranks itself (fresh child processes, before anything touches a GPU).
 """
 import argparse
 import json
@@ -31,7 +33,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="trace rows = 2^log_n (headline: 20)")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=12, help="rows of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=13, help="rows of the whole-prove() leg of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="ecdsa", choices=["ecdsa", "zkdsa-batch"],
                     help="ecdsa: the headline 2^20-row proof (default); zkdsa-batch: BASELINE config 5, a batch of independent "
@@ -99,26 +101,91 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(sample_log_n, full_log_n):
-    """Times the oracle (CPU restatement of plonky2's prove(), kind="port") on a bounded sample of the
-    same workload: the same synthetic ECDSA-shaped circuit with 2^sample_log_n rows, OpenMP over the cores this
-    process may use (`cores` = that number).  The port is a plain restatement (radix-2 FFT per column, naive Poseidon,
-    extension-field gate evaluation), several times slower than an optimised CPU prover would be: a baseline, not a target."""
+def cpu_baseline(full_log_n, sample_log_n, gpu_proof=None, gpu_circuit_desc=None, cs_cap=None):
+    """The oracle (CPU restatement of plonky2's prove(), kind="port") timed on this host's cores, on a bounded sample of
+    the headline workload, with NO extrapolation of the commitment half over rows:
+      (a) PolynomialBatch::from_values (iNTT + LDE x8 + Poseidon Merkle tree) at the FULL n = 2^full_log_n rows on 8 and
+          on 16 columns.  The cost is affine in the column count (every column is one iNTT + one LDE; every 8 columns one
+          more sponge permutation per leaf; the tree above the leaves does not depend on it):
+          t(c) = F + (c / 8) M, M = t(16) - t(8), F = 2 t(8) - t(16).  The proof commits 136 + 20 + 16 columns in three
+          batches: 3 F + 21.5 M.
+      (b) everything else (partial products, quotient evaluation, openings, FRI) = whole prove() at 2^sample_log_n rows
+          minus the three commitments measured at that size, scaled by the row ratio (these stages are pointwise in the
+          rows; the n log n terms among them are the small quotient / FRI transforms).
+    The port is a plain restatement (radix-2 FFT per column, naive 30-round Poseidon, extension-field gate evaluation),
+    several times slower than an optimised CPU prover: a baseline, not a target.  Also runs the oracle VERIFIER on the
+    proof the GPU just produced (checker role)."""
+    import numpy as np
     from oracle import oracle
     import plonky2_lib_amd.synth as synth
     oracle.build()
     cores = max(1, min(oracle.max_threads(), usable_cores()))
     oracle.set_threads(cores)
-    desc = synth.ecdsa_shape_circuit(sample_log_n, seed=SEED)
+    out = {"unit": "proofs/sec", "cores": cores, "kind": "port"}
+    if gpu_proof is not None:
+        oc = oracle.OracleCircuit(gpu_circuit_desc, cs_cap=cs_cap)
+        out["oracle_verifier_accepts_gpu_proof"] = bool(oc.verify(gpu_proof) == 0)
+    rng = np.random.default_rng(SEED)
+    n = 1 << full_log_n
+    t = {}
+    for ncols in (8, 16):
+        vals = oracle.rand_field(rng, (ncols, n))
+        t0 = time.perf_counter()
+        oracle.batch_from_values(vals, 3, 4)
+        t[ncols] = time.perf_counter() - t0
+        del vals
+    M, F = t[16] - t[8], 2 * t[8] - t[16]
+    commit_full = 3 * F + (136 + 20 + 16) / 8.0 * M
+    lgs = min(sample_log_n, full_log_n)
+    desc = synth.ecdsa_shape_circuit(lgs, seed=SEED)
     oc = oracle.OracleCircuit(desc)
     t0 = time.perf_counter()
     rc, proof = oc.prove()
-    t = time.perf_counter() - t0
+    t_prove = time.perf_counter() - t0
     assert rc == 0
-    frac = float(1 << sample_log_n) / float(1 << full_log_n)
-    return {"value": frac / t, "unit": "proofs/sec", "cores": cores, "kind": "port",
-            "sample": "oracle prove() of the same synthetic circuit at 2^%d of 2^%d rows: %.2f s wall, scaled "
-                      "linearly by row count" % (sample_log_n, full_log_n, t)}
+    t_commit_s = 0.0
+    for ncols in (136, 20, 16):
+        vals = oracle.rand_field(rng, (ncols, 1 << lgs))
+        t0 = time.perf_counter()
+        oracle.batch_from_values(vals, 3, 4)
+        t_commit_s += time.perf_counter() - t0
+    rest = max(t_prove - t_commit_s, 0.0) * float(1 << (full_log_n - lgs))
+    total = commit_full + rest
+    out["value"] = 1.0 / total
+    out["seconds_per_proof_estimate"] = round(total, 2)
+    out["ntt_merkle_seconds_at_full_size"] = round(commit_full, 2)
+    out["sample"] = ("oracle PolynomialBatch::from_values at the full 2^%d rows on 8 columns (%.2f s) and 16 columns (%.2f s) -> "
+                     "3 F + 21.5 M = %.1f s for the three commitments of one proof (affine in columns, no row extrapolation); "
+                     "other stages: oracle prove() of the same synthetic circuit at 2^%d rows (%.2f s) minus its three "
+                     "commitments (%.2f s), times 2^%d = %.1f s" % (full_log_n, t[8], t[16], commit_full, lgs, t_prove,
+                                                                     t_commit_s, full_log_n - lgs, rest))
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as torch.distributed.run would), BEFORE this process makes
+    any GPU call; rank 0's JSON line is the output.  Exit code = the worst child's."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()          # counts devices without initialising one (this image)
+    if a.force_device is None and ndev < a.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (a.gpus, ndev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    raise SystemExit(rc)
 
 
 def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
@@ -171,6 +238,10 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a)                 # never returns; nothing above this line touches a GPU
     import numpy as np
     import torch
     import plonky2_lib_amd as glp
@@ -181,6 +252,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: libglprover has no CPU path")
     grp = gdist.init_from_env(use_cuda=True, backend=a.dist_backend, force_device=a.force_device)
     rank, world = grp.rank, grp.world
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: the launcher and the flag disagree" % (a.gpus, world))
     local_rank = grp.local_rank if a.force_device is None else a.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -204,21 +277,19 @@ def main():
         c2 = glp.Context(local_rank)
         extra.append((c2, glp.Circuit(c2, desc_full)))
     keep_for_variant = world == 1 and max(a.inflight, 1) == 1 and not a.no_variants
-    consts_sigmas = (desc.constants, desc.sigmas) if keep_for_variant else None
-    desc.constants = desc.sigmas = None
-    desc_full = None
+    last_proof = [None]
 
     def step():
         if not extra:
-            return circuit.prove_device(wires.data_ptr())
+            last_proof[0] = circuit.prove_device(wires.data_ptr())
+            return
         import threading
         th = [threading.Thread(target=cc.prove_device, args=(wires.data_ptr(),)) for _, cc in extra]
         for t in th:
             t.start()
-        out = circuit.prove_device(wires.data_ptr())
+        last_proof[0] = circuit.prove_device(wires.data_ptr())
         for t in th:
             t.join()
-        return out
 
     for _ in range(a.warmup):
         step()
@@ -231,6 +302,11 @@ def main():
             c2.synchronize()
         torch.cuda.synchronize()
     dt = gdist.timed_steps(grp, step, a.steps, 0, device_sync)
+
+    # every rank checks the last proof of its timed loop with the library's verifier (`data.verify(proof)`, host code,
+    # [REF src/ecdsa/gadgets/ecdsa.rs:349-352]: prove THEN verify); outside the timed region
+    ok_local = bool(circuit.verify(last_proof[0])) if last_proof[0] is not None else False
+    ok_all = grp.max_over_ranks(0.0 if ok_local else 1.0) == 0.0
 
     # per-stage device times (hipEvents on the library's own stream), averaged per launch
     raw = ctx.stages()
@@ -282,10 +358,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u64 (Goldilocks, 64-bit modular integer)",
             "data": "synthetic",
+            "verified": ok_all,
+            "verified_by": "glp_verify (CircuitData::verify restatement, host code) on the last proof of every rank's timed loop",
             "config": {
                 "workload": "ECDSA-verify-shaped circuit (standard_ecc_config: 2^%d rows x 136 wires, 80 routed, 2 challenges, "
-                            "rate_bits 3, cap_height 4, 28 FRI queries, 16 PoW bits; all 11 gate types the reference registers for "
-                            "its secp256k1 circuit -- Arithmetic, BaseSum<4>, Comparison, Constant, RandomAccess(4), U32Arithmetic, "
+                            "rate_bits 3, cap_height 4, 28 FRI queries, 16 PoW bits; the 11 gate types SURVEY.md section 8 row Q lists as "
+                            "instantiated by the secp256k1 circuit (of the 21 its serializer registers) -- Arithmetic, BaseSum<4>, "
+                            "Comparison, Constant, RandomAccess(4), U32Arithmetic, "
                             "U32AddMany, U32RangeCheck, U32Subtraction, PublicInput, Noop -- in 3 selector groups, copy constraints); "
                             "one full prove() per step from an HBM-resident witness: wires commit, partial products, quotient, "
                             "openings, FRI, PoW, queries" % lg,
@@ -321,15 +400,29 @@ def main():
                 "stages": stage_out,
             },
         }
-        if consts_sigmas is not None:
-            # outside the timed region and outside `value`: the same proof with TWO in flight on this GPU (second context,
-            # stream and host thread), the deployment setting for a batch of independent proofs
+        if keep_for_variant:
+            # outside the timed region and outside `value`
             import threading
             ctx.set_profiling(False)
-            desc.constants, desc.sigmas = consts_sigmas
+            out["variants"] = {}
+            # (1) what `data.prove(pw)` does from a Rust caller: the witness starts in HOST memory (glp_prove uploads it in
+            # column chunks overlapped with the transforms); PCIe-inclusive, never `value`
+            host_wires = np.ascontiguousarray(desc.wires)
+            circuit.prove(wires=host_wires)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ph = circuit.prove(wires=host_wires)
+            ctx.synchronize()
+            dth = (time.perf_counter() - t0) / 3
+            out["variants"]["witness_from_host_memory"] = {
+                "value": 1.0 / dth, "unit": "proofs/sec", "ms_per_proof": dth * 1e3,
+                "same_proof_as_resident": bool((ph == last_proof[0]).all()),
+                "note": "PCIe-inclusive (1.14 GB pageable host witness per proof); not the headline value"}
+            # (2) the same proof with TWO in flight on this GPU (second context, stream and host thread), the deployment
+            # setting for a batch of independent proofs
             c2 = glp.Context(local_rank)
             cc2 = glp.Circuit(c2, desc)
-            desc.constants = desc.sigmas = None
 
             def pair():
                 t = threading.Thread(target=cc2.prove_device, args=(wires.data_ptr(),))
@@ -343,13 +436,19 @@ def main():
                 pair()
             ctx.synchronize(); c2.synchronize()
             dt2 = time.perf_counter() - t0
-            out["variants"] = {"two_proofs_in_flight_per_gpu": {"value": 6.0 / dt2, "unit": "proofs/sec",
-                               "note": "not the headline value: stage timings above are taken with one proof in flight"}}
+            out["variants"]["two_proofs_in_flight_per_gpu"] = {
+                "value": 6.0 / dt2, "unit": "proofs/sec",
+                "note": "not the headline value: stage timings above are taken with one proof in flight"}
             cc2.free()
             c2.close()
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(a.cpu_sample_log_n, lg), lg)
+            desc.circuit_digest = circuit.digest()
+            out["cpu_baseline"] = cpu_baseline(lg, a.cpu_sample_log_n, gpu_proof=last_proof[0], gpu_circuit_desc=desc,
+                                               cs_cap=circuit.constants_sigmas_cap())
         print(json.dumps(out))
+        sys.stdout.flush()
+    if not ok_all:
+        raise SystemExit("bench.py: glp_verify REJECTED a proof from the timed loop")
     for c2, cc in extra:
         cc.free()
         c2.close()

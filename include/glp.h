@@ -253,6 +253,9 @@ GLP_API void glp_session_end(glp_session *s);
  * combination, arity-2^k consistency, final polynomial).  Host computation (a few thousand Poseidon permutations), no
  * device work.  GLP_OK = accepted; GLP_ERR_PROVE with the reason in glp_last_error() = rejected. */
 GLP_API int glp_verify(const glp_circuit *circuit, const uint64_t *proof_words);
+/* The same with the buffer length stated (num_words must equal glp_proof_words(circuit)): for callers that hold a proof of
+ * unknown provenance; a wrong length is GLP_ERR_ARG, not a read past the buffer. */
+GLP_API int glp_verify_n(const glp_circuit *circuit, const uint64_t *proof_words, size_t num_words);
 
 /* plonky2 `ProofWithPublicInputs::to_bytes()` (util/serialization.rs `Buffer::write_proof_with_public_inputs`):
  * every field element as 8 little-endian bytes in the word order above, plus the one-byte sibling

@@ -125,6 +125,7 @@ def load_library():
         "glp_session_proof": [vp, vp],
         "glp_session_end": [vp],
         "glp_verify": [vp, vp],
+        "glp_verify_n": [vp, vp, sz],
         "glp_dev_alloc": [vp, sz, C.POINTER(vp)],
         "glp_dev_free": [vp, vp],
         "glp_dev_upload": [vp, vp, vp, sz],
@@ -353,6 +354,19 @@ class Circuit:
             for f, _ in _Gate._fields_:
                 setattr(gates[i], f, int(g[f]))
         k, const, sig = _a(desc.k_is), _a(desc.constants), _a(desc.sigmas)
+        # the C ABI takes bare pointers: every array's size is checked here so that a wrong shape is a GlpError, not a
+        # host over-read
+        n = 1 << int(desc.degree_bits)
+        if k.size != int(desc.num_routed_wires):
+            raise GlpError(-1, "k_is has %d entries, num_routed_wires is %d" % (k.size, desc.num_routed_wires))
+        if const.size != int(desc.num_constants) * n:
+            raise GlpError(-1, "constants has %d elements, expected num_constants * 2^degree_bits = %d" % (const.size, int(desc.num_constants) * n))
+        if sig.size != int(desc.num_routed_wires) * n:
+            raise GlpError(-1, "sigmas has %d elements, expected num_routed_wires * 2^degree_bits = %d" % (sig.size, int(desc.num_routed_wires) * n))
+        if len(desc.reduction_arity_bits) > 16:
+            raise GlpError(-1, "more than 16 FRI reductions")
+        self._wire_elems = int(desc.num_wires) * n
+        self._num_pis = int(len(desc.public_inputs))
         d = _CircuitDesc()
         for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
                   "quotient_degree_factor", "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
@@ -398,14 +412,28 @@ class Circuit:
         """`data.prove(pw)` after witness generation: full witness in, proof words out (include/glp.h)."""
         w = _a(self.desc.wires if wires is None else wires)
         pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)
+        self._check_witness(w, pi)
         proof = np.zeros(self.proof_words, np.uint64)
         _chk(load_library().glp_prove(self.ctx._h, self._h, _p(w), _p(pi) if pi.size else None, _p(proof)))
         return proof
 
+    def _check_witness(self, w, pi):
+        if w is not None and w.size != self._wire_elems:
+            raise GlpError(-1, "wires has %d elements, expected num_wires * 2^degree_bits = %d" % (w.size, self._wire_elems))
+        if pi.size != self._num_pis:
+            raise GlpError(-1, "%d public inputs, the circuit has %d" % (pi.size, self._num_pis))
+
+    def _check_proof(self, proof_words):
+        a = _a(proof_words)
+        if a.size != self.proof_words:
+            raise GlpError(-1, "proof has %d words, a proof of this circuit has %d" % (a.size, self.proof_words))
+        return a
+
     def verify(self, proof_words):
         """`data.verify(proof)`: True if accepted; raises nothing on rejection (reason: `last_error()`)."""
         L = load_library()
-        rc = L.glp_verify(self._h, _p(_a(proof_words)))
+        a = _a(proof_words)
+        rc = L.glp_verify_n(self._h, _p(a), a.size)
         if rc == 0:
             return True
         if rc == -5:          # GLP_ERR_PROVE: a well-formed call, the proof is rejected
@@ -417,7 +445,7 @@ class Circuit:
         L = load_library()
         n = L.glp_proof_bytes_len(self._h)
         out = np.empty(n, np.uint8)
-        _chk(L.glp_proof_to_bytes(self._h, _p(_a(proof_words)), out.ctypes.data_as(C.c_void_p), n))
+        _chk(L.glp_proof_to_bytes(self._h, _p(self._check_proof(proof_words)), out.ctypes.data_as(C.c_void_p), n))
         return out.tobytes()
 
     def proof_from_bytes(self, data):
@@ -428,6 +456,7 @@ class Circuit:
 
     def prove_device(self, dev_wires_ptr, public_inputs=None):
         pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)
+        self._check_witness(None, pi)
         proof = np.zeros(self.proof_words, np.uint64)
         _chk(load_library().glp_prove_device(self.ctx._h, self._h, C.c_void_p(dev_wires_ptr), _p(pi) if pi.size else None,
                                              _p(proof)))
@@ -448,9 +477,11 @@ class Session:
         self.wires_cap = np.empty((self._capn, 4), np.uint64)
         self.public_inputs_hash = np.empty(4, np.uint64)
         if dev_wires_ptr is not None:
+            circuit._check_witness(None, pi)
             wp, on_dev = C.c_void_p(dev_wires_ptr), 1
         else:
             self._w = _a(d.wires if wires is None else wires)     # keep the host array alive
+            circuit._check_witness(self._w, pi)
             wp, on_dev = _p(self._w), 0
         _chk(L.glp_session_begin(circuit.ctx._h, circuit._h, wp, on_dev, _p(pi) if pi.size else None, C.byref(self._h),
                                  _p(self.wires_cap), _p(self.public_inputs_hash)))

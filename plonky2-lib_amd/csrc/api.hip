@@ -101,7 +101,13 @@ int glp_ctx_create(int device_id, glp_ctx **out) {
     c->device = device_id;
     c->num_cus = prop.multiProcessorCount;
     GLP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    GLP_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    {
+        hipError_t e2 = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+        if (e2 != hipSuccess) {
+            (void)hipStreamDestroy(c->stream);
+            return set_error(GLP_ERR_HIP, "hipStreamCreateWithFlags (copy stream): %s", hipGetErrorString(e2));
+        }
+    }
     *out = c.release();
     return GLP_OK;
 }
@@ -142,9 +148,20 @@ int glp_dev_free(glp_ctx *c, void *dev) {
     c->release(dev);
     return GLP_OK;
 }
+// the live block of this context that contains [p, p + bytes), or an error: a copy never runs past an allocation
+static int check_dev_range(glp_ctx *c, const void *p, size_t bytes) {
+    auto it = c->live.upper_bound(const_cast<void *>(p));
+    GLP_REQUIRE(it != c->live.begin(), "device pointer is not inside an allocation of this context");
+    --it;
+    const char *b0 = (const char *)it->first, *q = (const char *)p;
+    GLP_REQUIRE(q >= b0 && (size_t)(q - b0) <= it->second && bytes <= it->second - (size_t)(q - b0),
+                "%zu bytes at offset %zu run past the end of a %zu-byte device block", bytes, (size_t)(q - b0), it->second);
+    return GLP_OK;
+}
 int glp_dev_upload(glp_ctx *c, void *dev_dst, const void *host_src, size_t bytes) {
     GLP_REQUIRE(c && dev_dst && host_src, "null argument");
     GLP_TRY(bind(c));
+    GLP_TRY(check_dev_range(c, dev_dst, bytes));
     GLP_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
     GLP_HIP(hipStreamSynchronize(c->stream));
     return GLP_OK;
@@ -152,6 +169,7 @@ int glp_dev_upload(glp_ctx *c, void *dev_dst, const void *host_src, size_t bytes
 int glp_dev_download(glp_ctx *c, void *host_dst, const void *dev_src, size_t bytes) {
     GLP_REQUIRE(c && host_dst && dev_src, "null argument");
     GLP_TRY(bind(c));
+    GLP_TRY(check_dev_range(c, dev_src, bytes));
     GLP_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
     GLP_HIP(hipStreamSynchronize(c->stream));
     return GLP_OK;
@@ -249,6 +267,7 @@ int glp_lde(glp_ctx *c, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, 
             uint64_t *out) {
     GLP_REQUIRE(c && ((coeffs && out) || !ncols), "null argument");
     GLP_REQUIRE(shift != 0 && shift < glf::P, "shift must be a nonzero canonical field element");
+    if (rate_bits > 4) return set_error(GLP_ERR_UNSUPPORTED, "rate_bits=%u outside 0..4", rate_bits);
     GLP_TRY(bind(c));
     if (!ncols) return GLP_OK;
     if (log_n > (uint32_t)NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%u > %d", log_n, NTT_MAX_LG);

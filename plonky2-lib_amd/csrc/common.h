@@ -55,6 +55,7 @@ struct glp_ctx {
     size_t pool_bytes = 0;
     std::map<int, glp::NttPlan *> ntt_plans;                       // key: log_n
     std::map<std::pair<std::pair<int, int>, u64>, glp::LdePlan *> lde_plans;  // key: ((log_n, rate_bits), shift)
+    unsigned long long lde_clock = 0;                              // LRU stamps for lde_plans
     bool profiling = false;
     std::vector<glp::Stage> stages;
 

@@ -31,6 +31,12 @@ struct NttPlan {
     const NttPlan *inner = nullptr;          // the 2^20 plan
     u64 *tw_Ao = nullptr, *itw_Ao = nullptr; // w_A'^(+-j), j < A'/2
     u64 *it0 = nullptr, *it1 = nullptr;      // inverse outer twiddle: (w_n^-k1o)^q = it1[pbo][q >> 10] * it0[pbo][q & 1023], it1 carries 1/A'
+    NttPlan() = default;
+    NttPlan(const NttPlan &) = delete;
+    NttPlan &operator=(const NttPlan &) = delete;
+    ~NttPlan() {                             // tables belong to the plan: an error path that drops a half-built plan frees them
+        for (u64 *t : {tw_B, itw_B, tw_A, itw_A, tw4096, itw4096, tw_Ao, itw_Ao, it0, it1}) if (t) (void)hipFree(t);
+    }
 };
 
 struct LdePlan {
@@ -42,7 +48,14 @@ struct LdePlan {
     // lg > NTT_2PASS_LG only
     const LdePlan *inner = nullptr;          // (2^20, rate_bits, shift^A')
     u64 *t0 = nullptr, *t1 = nullptr;        // outer twiddle s_r^k1o (w_n^k1o)^q = t1[r][pbo][q >> 10] * t0[pbo][q & 1023]
+    u64 last_use = 0;                        // LRU stamp (glp_ctx::lde_clock); plans other LdePlans point at are pinned
+    int pins = 0;
+    LdePlan() = default;
+    LdePlan(const LdePlan &) = delete;
+    LdePlan &operator=(const LdePlan &) = delete;
+    ~LdePlan() { for (u64 *t : {pre, s_r, t0, t1}) if (t) (void)hipFree(t); }
 };
+constexpr size_t LDE_PLAN_CACHE_MAX = 48;    // distinct (log_n, rate_bits, shift) tables kept per context
 
 int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out);
 int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out);

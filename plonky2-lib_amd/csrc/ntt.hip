@@ -90,7 +90,19 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
     if (rate_bits < 0 || rate_bits > 4) return set_error(GLP_ERR_UNSUPPORTED, "rate_bits=%d outside 0..4", rate_bits);
     auto key = std::make_pair(std::make_pair(lg, rate_bits), shift);
     auto it = c->lde_plans.find(key);
-    if (it != c->lde_plans.end()) { *out = it->second; return GLP_OK; }
+    if (it != c->lde_plans.end()) { it->second->last_use = ++c->lde_clock; *out = it->second; return GLP_OK; }
+    // The cache is keyed by the caller-supplied shift (glp_lde, FRI layers): bound it.  Evict the least recently used
+    // plan that no other plan points at; nothing is in flight that could read it only if the stream is idle, so wait.
+    while (c->lde_plans.size() >= LDE_PLAN_CACHE_MAX) {
+        auto victim = c->lde_plans.end();
+        for (auto jt = c->lde_plans.begin(); jt != c->lde_plans.end(); ++jt)
+            if (jt->second->pins == 0 && (victim == c->lde_plans.end() || jt->second->last_use < victim->second->last_use)) victim = jt;
+        if (victim == c->lde_plans.end()) break;
+        GLP_HIP(hipStreamSynchronize(c->stream));
+        if (victim->second->inner) const_cast<LdePlan *>(victim->second->inner)->pins--;
+        delete victim->second;
+        c->lde_plans.erase(victim);
+    }
     NttPlan *np;
     GLP_TRY(get_ntt_plan(c, lg, &np));
     std::unique_ptr<LdePlan> p(new LdePlan());
@@ -101,6 +113,8 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
         LdePlan *in;
         GLP_TRY(get_lde_plan(c, NTT_2PASS_LG, rate_bits, pow(shift, (u64)Ao), &in));
         p->inner = in;
+        in->pins++;
+        struct Unpin { LdePlan *q; ~Unpin() { if (q) q->pins--; } } unpin{in};     // undone if this plan is not completed
         const u64 Wbig = root_of_unity(lg + rate_bits);
         std::vector<u64> t0(Ao * 1024), t1((size_t)R * Ao * 1024);
         for (size_t pbo = 0; pbo < Ao; pbo++) {
@@ -115,6 +129,8 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
         }
         GLP_TRY(upload(c, t0, &p->t0));
         GLP_TRY(upload(c, t1, &p->t1));
+        unpin.q = nullptr;
+        p->last_use = ++c->lde_clock;
         *out = p.get();
         c->lde_plans[key] = p.release();
         return GLP_OK;
@@ -134,23 +150,16 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
     }
     GLP_TRY(upload(c, s, &p->s_r));
     GLP_TRY(upload(c, pre, &p->pre));
+    p->last_use = ++c->lde_clock;
     *out = p.get();
     c->lde_plans[key] = p.release();
     return GLP_OK;
 }
 
 void free_plans(glp_ctx *c) {
-    for (auto &kv : c->lde_plans) {
-        (void)hipFree(kv.second->pre); (void)hipFree(kv.second->s_r); (void)hipFree(kv.second->t0); (void)hipFree(kv.second->t1);
-        delete kv.second;
-    }
+    for (auto &kv : c->lde_plans) delete kv.second;       // the plans' destructors free their tables
     c->lde_plans.clear();
-    for (auto &kv : c->ntt_plans) {
-        (void)hipFree(kv.second->tw_B); (void)hipFree(kv.second->itw_B); (void)hipFree(kv.second->tw_A); (void)hipFree(kv.second->itw_A);
-        (void)hipFree(kv.second->tw4096); (void)hipFree(kv.second->itw4096);
-        (void)hipFree(kv.second->tw_Ao); (void)hipFree(kv.second->itw_Ao); (void)hipFree(kv.second->it0); (void)hipFree(kv.second->it1);
-        delete kv.second;
-    }
+    for (auto &kv : c->ntt_plans) delete kv.second;
     c->ntt_plans.clear();
 }
 

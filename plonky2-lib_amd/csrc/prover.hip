@@ -1247,6 +1247,9 @@ struct glp_session {
     }
 };
 
+// One bound for glp_circuit_create and glp_pow_search: with the search capped at 2^40 candidates, 32 bits leaves a failure
+// probability of exp(-2^8).
+constexpr u32 POW_MAX_BITS = 32;
 // K10: smallest witness w >= 0 such that the sponge (state + pending inputs + w) squeezes a value with `bits` leading
 // zeros.  The search covers candidates in increasing order, so the result does not depend on launch geometry.
 static int pow_search(glp_ctx *c, const u64 st[12], const u64 *pending, u32 npending, u32 bits, u64 *witness) {
@@ -1379,7 +1382,8 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         return set_error(GLP_ERR_UNSUPPORTED, "quotient_degree_factor=%u must be a power of two <= 2^rate_bits", qdf);
     GLP_REQUIRE(d.num_partial_products == (d.num_routed_wires + qdf - 1) / qdf - 1, "num_partial_products inconsistent");
     GLP_REQUIRE(d.num_reductions <= 16 && d.cap_height <= d.degree_bits + d.rate_bits, "bad FRI parameters");
-    GLP_REQUIRE(d.proof_of_work_bits < 40, "proof_of_work_bits too large");
+    GLP_REQUIRE(d.proof_of_work_bits <= POW_MAX_BITS, "proof_of_work_bits=%u: this build searches at most 2^40 candidates and accepts up to %u bits",
+                d.proof_of_work_bits, POW_MAX_BITS);
     u32 sum_ab = 0;
     for (u32 i = 0; i < d.num_reductions; i++) {
         GLP_REQUIRE(d.reduction_arity_bits[i] >= 1 && d.reduction_arity_bits[i] <= 5, "arity_bits outside 1..5");
@@ -1633,7 +1637,8 @@ int glp_session_fri_final_poly(glp_session *s, uint64_t *coeffs_out) {
 int glp_pow_search(glp_ctx *c, const uint64_t sponge_state[12], const uint64_t *pending_inputs, uint32_t num_pending, uint32_t bits,
                    uint64_t *witness_out) {
     GLP_REQUIRE(c && sponge_state && witness_out && (pending_inputs || num_pending == 0), "null argument");
-    GLP_REQUIRE(bits <= 40, "proof_of_work_bits=%u: the search stops at 2^40 candidates", bits);
+    GLP_REQUIRE(bits <= POW_MAX_BITS, "proof_of_work_bits=%u: this build searches at most 2^40 candidates and accepts up to %u bits", bits,
+                POW_MAX_BITS);
     GLP_TRY(bind(c));
     return pow_search(c, sponge_state, pending_inputs, num_pending, bits, witness_out);
 }

@@ -436,3 +436,9 @@ extern "C" int glp_verify(const glp_circuit *cc, const uint64_t *proof_words) {
     GLP_REQUIRE(cc && proof_words, "null argument");
     return verify_impl(cc, proof_words);
 }
+// Same, with the caller's buffer length stated: a truncated or over-long buffer is an argument error, never a read past it.
+extern "C" int glp_verify_n(const glp_circuit *cc, const uint64_t *proof_words, size_t num_words) {
+    GLP_REQUIRE(cc && proof_words, "null argument");
+    GLP_REQUIRE(num_words == cc->L.total, "proof has %zu words, a proof of this circuit has %zu", num_words, (size_t)cc->L.total);
+    return verify_impl(cc, proof_words);
+}

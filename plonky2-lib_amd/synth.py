@@ -42,6 +42,11 @@ _GATE_META = {
 }
 
 
+def gate_degree(t, p0=0, p1=0):
+    """`Gate::degree`: fixed per type except BaseSumGate<B> (the range product has B factors)."""
+    return p1 if t == GATE_BASE_SUM else _GATE_META[t][0]
+
+
 def gate_num_constraints(t, p0, p1=0):
     if t == GATE_U32_ADD_MANY:
         return p1 * 21
@@ -146,8 +151,8 @@ class Builder:
         cfg, n, lg = self.cfg, self.n, self.log_n
         c = Circuit()
         kinds = sorted(self.gate_kinds.items(),
-                       key=lambda kv: (_GATE_META[kv[0][0]][0], _GATE_META[kv[0][0]][1].format(p0=kv[0][1], p1=kv[0][2])))
-        gates = [(_GATE_META[t][0], t, p0, p1) for (t, p0, p1), _ in kinds]
+                       key=lambda kv: (gate_degree(*kv[0]), _GATE_META[kv[0][0]][1].format(p0=kv[0][1], p1=kv[0][2])))
+        gates = [(gate_degree(t, p0, p1), t, p0, p1) for (t, p0, p1), _ in kinds]
         key_to_index = {key: i for i, (_, key) in enumerate(kinds)}
         sel_idx, groups = _selector_groups(gates, cfg.max_quotient_degree_factor + 1)
         num_selectors = len(groups)
@@ -575,4 +580,88 @@ def poseidon_chain_circuit(log_n, config=None, seed=6):
         zeros += [(r, 24)] + [(r, 8 + i) for i in range(4)]
         cur, prev = out[:4], r
     b.connect_cycle([r for r, _ in zeros], [c for _, c in zeros])
+    return b.build()
+
+
+def _fill_arith_rows(b, rows_a):
+    """ArithmeticGate rows (20 ops wide at 80 routed wires): per-row constants c0, c1; out_j = c0 m0 m1 + c1 addend, each
+    output copy-constrained into the next op's addend; m1 of op 0 is one cycle through all rows."""
+    cfg = b.cfg
+    num_ops = cfg.num_routed_wires // 4
+    na = len(rows_a)
+    if na == 0:
+        return
+    b.set_rows(rows_a, GATE_ARITHMETIC, num_ops)
+    c01 = gl.rand(b.rng, (2, na))
+    b.gate_consts[0, rows_a], b.gate_consts[1, rows_a] = c01[0], c01[1]
+    b.wires[1, rows_a] = gl.rand(b.rng, 1)[0]
+    b.connect_cycle(rows_a, np.full(na, 1))
+    for j in range(num_ops):
+        m0, m1, ad = b.wires[4 * j, rows_a], b.wires[4 * j + 1, rows_a], b.wires[4 * j + 2, rows_a]
+        out = gl.add(gl.mul(gl.mul(m0, m1), c01[0]), gl.mul(ad, c01[1]))
+        b.wires[4 * j + 3, rows_a] = out
+        if j + 1 < num_ops:
+            b.wires[4 * (j + 1) + 2, rows_a] = out
+            b.connect_pairs(rows_a, 4 * j + 3, rows_a, 4 * (j + 1) + 2)
+
+
+def smt_shape_circuit(log_n, config=None, seed=7, levels=16):
+    """BASELINE config 4 stand-in: the gate mix of the sparse-Merkle-tree inclusion circuit
+    [REF src/smt/gadgets/verify/verify_smt.rs:214-307, src/smt/gadgets/common.rs:87-112], `standard_recursion_config`.
+    One inclusion proof of `levels` levels instantiates: 2 leaf hashes of 12 inputs (2 permutations each) + one
+    two-to-one hash per level = levels + 4 PoseidonGate rows [common.rs:87-101,16-25]; `split_le(key[i], 64)` for the four
+    key elements [verify_smt.rs:240-242] = 8 BaseSumGate<2> rows (63 limbs per gate at 80 routed wires: a 63-bit gate and a
+    1-bit gate per element); the level state machine, conditional selects and equality checks = ArithmeticGate ops
+    (about 30 per level, 20 ops per row).  The trace is filled with that proportion (levels + 4 : 8 : 1.5 levels),
+    repeated as in a batch of inclusion proofs; ConstantGate / PublicInputGate / NoopGate as in every circuit.
+    Rows: [PublicInput][Constant x2][Poseidon chain ...][BaseSum<2> ...][Arithmetic ...][Noop x2]."""
+    cfg = config or Config.standard_recursion_config()
+    b = Builder(cfg, log_n, seed)
+    n = b.n
+    if n < 16:
+        raise ValueError("log_n too small")
+    body = n - 5
+    wp, wb, wa = levels + 4, 8, (3 * levels + 1) // 2
+    n_p = max(1, body * wp // (wp + wb + wa))
+    n_b = max(2, body * wb // (wp + wb + wa))
+    rows_p = list(range(3, 3 + n_p))
+    rows_b = list(range(3 + n_p, 3 + n_p + n_b))
+    rows_a = np.arange(3 + n_p + n_b, n - 2)
+    rows_c = np.array([1, 2])
+    b.set_rows(np.array([0]), GATE_PUBLIC_INPUT, 0)
+    b.set_rows(rows_c, GATE_CONSTANT, cfg.num_constants)
+    b.set_rows(np.array(rows_p), GATE_POSEIDON, 0)
+    b.gate_consts[:, rows_c] = 0
+    b.wires[:cfg.num_constants, rows_c] = 0
+    b.wires[:4, 0] = 0
+    # Poseidon rows: chains of `levels` two-to-one hashes, each absorbing the previous digest and a sibling
+    zeros = [(1, 0), (0, 0), (0, 1), (0, 2), (0, 3)]
+    cur, prev = None, None
+    for t, r in enumerate(rows_p):
+        if t % (levels + 4) == 0:
+            cur, prev = [int(x) for x in gl.rand(b.rng, 4)], None
+        sib = [int(x) for x in gl.rand(b.rng, 4)]
+        out = _fill_poseidon_row(b, r, cur + sib + [0] * 4)
+        if prev is not None:
+            for i in range(4):
+                b.connect_cycle([prev, r], [12 + i, i])
+        zeros += [(r, 24)] + [(r, 8 + i) for i in range(4)]
+        cur, prev = out[:4], r
+    b.connect_cycle([r for r, _ in zeros], [c for _, c in zeros])
+    # BaseSumGate<2>, 63 limbs: alternately a 63-bit value and a single bit (the two gates of one split_le(x, 64))
+    nl = min(cfg.num_routed_wires - 1, 63)
+    for t, r in enumerate(rows_b):
+        b.set_rows(np.array([r]), GATE_BASE_SUM, nl, 2)
+        v = int(b.rng.integers(0, 1 << 62)) * 2 + int(b.rng.integers(0, 2)) if t % 2 == 0 else int(b.rng.integers(0, 2))
+        b.wires[0, r] = v
+        b.wires[1:1 + nl, r] = _digits(v, 1, nl)
+    # the bit wires of a pair of split gates feed arithmetic rows in the real circuit; here: limb 0 of consecutive gates
+    # with equal values are tied (a copy constraint between BaseSum rows)
+    lim0 = {}
+    for r in rows_b:
+        lim0.setdefault(int(b.wires[1, r]), []).append(r)
+    for rows in lim0.values():
+        if len(rows) > 1:
+            b.connect_cycle(rows, [1] * len(rows))
+    _fill_arith_rows(b, rows_a)
     return b.build()

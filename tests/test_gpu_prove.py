@@ -145,6 +145,63 @@ def test_prove_parity_poseidon_chain(ctx, oracle):
     _check(ctx, oracle, synth.poseidon_chain_circuit(5))
 
 
+@pytest.mark.parametrize("lg", [5, 6, 7, 8])
+def test_prove_parity_smt_gate_mix(ctx, oracle, lg):
+    """BASELINE config 4 gate mix [REF src/smt/gadgets/verify/verify_smt.rs:214-307, src/smt/gadgets/common.rs:87-112]:
+    PoseidonGate chains, BaseSumGate<2> with 63 limbs (`split_le(key, 64)`), ArithmeticGate rows, Constant / PublicInput /
+    Noop, two selector groups.  Word-for-word against the oracle prover, both verifiers accept."""
+    desc = synth.smt_shape_circuit(lg, seed=70 + lg)
+    kinds = {(g["type"], g["p0"], g["p1"]) for g in desc.gates}
+    assert (synth.GATE_BASE_SUM, 63, 2) in kinds and (synth.GATE_POSEIDON, 0, 0) in kinds and (synth.GATE_ARITHMETIC, 20, 0) in kinds
+    _check(ctx, oracle, desc)
+
+
+def test_smt_shape_2_12_verifies(ctx, oracle):
+    """Config 4 at the size BASELINE.md lists (2^12 rows): proof accepted by both verifiers, a broken BaseSum<2> limb (2 is
+    not a bit) and a tampered proof word are rejected."""
+    desc = synth.smt_shape_circuit(12, seed=4)
+    gc = glp.Circuit(ctx, desc)
+    proof = gc.prove()
+    desc.circuit_digest = gc.digest()
+    oc = oracle.OracleCircuit(desc, cs_cap=gc.constants_sigmas_cap())
+    assert oc.verify(proof) == 0 and gc.verify(proof)
+    bad = proof.copy(); bad[777] = np.uint64((int(bad[777]) + 1) % glp.P)
+    assert oc.verify(bad) != 0 and not gc.verify(bad)
+    row_b = next(r for r in range(1 << 12) if int(desc.constants[0][r]) == next(i for i, g in enumerate(desc.gates) if g["type"] == synth.GATE_BASE_SUM))
+    w = desc.wires.copy()
+    w[5, row_b] = 2
+    assert not gc.verify(gc.prove(wires=w))
+    gc.free()
+
+
+def test_wrong_shapes_are_errors_not_overreads(ctx):
+    """The C ABI takes bare pointers; the binding checks every array against the circuit before the call."""
+    desc = synth.arith_circuit(5, synth.Config.standard_recursion_config(), seed=2)
+    gc = glp.Circuit(ctx, desc)
+    proof = gc.prove()
+    with pytest.raises(glp.GlpError):
+        gc.prove(wires=desc.wires[:, :16])
+    with pytest.raises(glp.GlpError):
+        gc.prove(public_inputs=[1, 2, 3])
+    with pytest.raises(glp.GlpError):
+        gc.verify(proof[:-1])                       # glp_verify_n: a truncated proof is an argument error
+    with pytest.raises(glp.GlpError):
+        gc.proof_to_bytes(proof[:100])
+    bad = synth.arith_circuit(5, synth.Config.standard_recursion_config(), seed=2)
+    bad.sigmas = bad.sigmas[:, :8]
+    with pytest.raises(glp.GlpError):
+        glp.Circuit(ctx, bad)
+    d = ctx.dev_alloc(4096)
+    with pytest.raises(glp.GlpError):
+        ctx.dev_upload(d, np.zeros(1024, np.uint64))          # 8192 bytes into a 4096-byte block
+    with pytest.raises(glp.GlpError):
+        ctx.dev_download(d + 4000, np.zeros(64, np.uint64))
+    ctx.dev_upload(d + 2048, np.zeros(256, np.uint64))        # inside the block at an offset: fine
+    ctx.dev_free(d)
+    with pytest.raises(glp.GlpError):
+        glp.load_library() and ctx.lde(np.zeros((1, 8), np.uint64), rate_bits=9)
+
+
 def test_unsatisfied_witness_fails_verification(ctx, oracle):
     desc = synth.arith_circuit(7, seed=11)
     oc = oracle.OracleCircuit(desc)
@@ -189,6 +246,35 @@ def test_prove_properties_2_16(ctx, oracle):
     assert (gc.prove() == p1).all()
     bad = p1.copy(); bad[1000] = np.uint64((int(bad[1000]) + 1) % glp.P)
     assert oc.verify(bad) != 0
+
+
+def test_headline_2_20_verifies(ctx, oracle):
+    """The exact circuit bench.py times (synth.ecdsa_shape_circuit(20): 2^20 rows x 136 wires, the 11-gate secp256k1
+    constraint set, the direct two-pass 2^20 transforms): the proof must satisfy BOTH verifiers (the oracle's and the
+    library's own), a tampered word must be rejected by both, and proving is deterministic
+    [REF src/bin/perf.rs:7-9, src/ecdsa/gadgets/ecdsa.rs:349-352: prove, then verify]."""
+    desc = synth.ecdsa_shape_circuit(20, seed=0x5EED0003)
+    assert len(desc.gates) == 11 and desc.num_wires == 136
+    gc = glp.Circuit(ctx, desc)
+    proof = gc.prove()
+    desc.circuit_digest = gc.digest()
+    oc = oracle.OracleCircuit(desc, cs_cap=gc.constants_sigmas_cap())
+    assert oc.verify(proof) == 0
+    assert gc.verify(proof)
+    w = np.ascontiguousarray(desc.wires)
+    dptr = ctx.dev_alloc(w.nbytes)
+    ctx.dev_upload(dptr, w)
+    assert (gc.prove_device(dptr) == proof).all()        # the entry point the bench times
+    ctx.dev_free(dptr)
+    rng = np.random.default_rng(20)
+    for pos in [int(x) for x in rng.integers(0, len(proof), 4)] + [0, len(proof) - 1]:
+        bad = proof.copy(); bad[pos] = np.uint64((int(bad[pos]) + 1) % glp.P)
+        assert oc.verify(bad) != 0 and not gc.verify(bad), pos
+    # an unsatisfied witness (one ArithmeticGate output off by one in the middle of the trace) must not verify
+    w2 = desc.wires.copy()
+    w2[3, 1 << 19] = np.uint64((int(w2[3, 1 << 19]) + 1) % glp.P)
+    assert not gc.verify(gc.prove(wires=w2))
+    gc.free()
 
 
 def test_prove_2_21_rows_verifies(ctx, oracle):

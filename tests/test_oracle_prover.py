@@ -115,3 +115,22 @@ def test_fri_reduction_schedule():
     assert cfg.reduction_arity_bits(20) == [4, 4, 4, 4]       # final polynomial of 16 coefficients
     assert cfg.reduction_arity_bits(12) == [4, 4]
     assert cfg.reduction_arity_bits(5) == []
+
+
+def test_smt_shape_circuit(oracle):
+    """Config 4 gate mix (PoseidonGate chains, BaseSumGate<2> x 63 limbs, ArithmeticGate): verify(prove(w)) accepts; a
+    limb that is not a bit and a broken hash chain are caught by the vanishing check."""
+    c = synth.smt_shape_circuit(6)
+    assert sorted((g["type"], g["p1"]) for g in c.gates) == [(0, 0), (1, 0), (2, 0), (3, 0), (4, 0), (13, 2)]
+    assert synth.gate_degree(synth.GATE_BASE_SUM, 63, 2) == 2 and synth.gate_degree(synth.GATE_BASE_SUM, 16, 4) == 4
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    bs = next(i for i, g in enumerate(c.gates) if g["type"] == synth.GATE_BASE_SUM)
+    row = next(r for r in range(c.constants.shape[1]) if int(c.constants[0][r]) == bs)
+    w = c.wires.copy(); w[7, row] = 2
+    rc, bad = oc.prove(wires=w)
+    assert oc.verify(bad) == 3
+    w = c.wires.copy(); w[13, 4] = np.uint64((int(w[13, 4]) + 1) % oracle.P)      # a Poseidon output
+    rc, bad = oc.prove(wires=w)
+    assert oc.verify(bad) == 3

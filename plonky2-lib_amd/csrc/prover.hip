@@ -254,23 +254,46 @@ struct QArgs {
     u64 w_n, n_field;
     u32 lg, rb, step, nc, nsel, nr, nw, nch, npp, qdf, num_gates, nterms, many_selectors, gate_mode;
     u32 k_ratio;                    // != 0: k_is[j] = k_ratio^j (plonky2's get_unique_coset_shifts: powers of the generator 7)
+    const u64 *l0;                  // [Rq][n]: L_0(x) = Z_H(x) / (n (x - 1)) on the evaluated planes (k_l0_table)
 };
-// Contribution of ONE gate at one point: filter(selector) * sum_k constraint_k * alpha_c^(k0 + k), added into acc[c].
-// TYPE >= 0 compiles a single gate body (per-gate kernels: small register footprint, high occupancy); TYPE = -1
-// keeps the run-time switch (monolithic fallback).
-template <int NCH, int TYPE>
-__device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
+// L_0 on the evaluated planes.  One thread owns position q of every plane and inverts the Rq denominators n (x_rq - 1)
+// with ONE field inversion (Montgomery's trick) instead of one per point inside k_quotient.
+__global__ __launch_bounds__(256) void k_l0_table(QArgs a, u64 *out, u32 Rq) {
+    const size_t n = (size_t)1 << a.lg;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u64 wq = dpow(a.w_n, q);
+    u64 d[MAXR], pre[MAXR];
+    u64 run = 1;
+    for (u32 rq = 0; rq < Rq; rq++) {            // x is never 1 on a coset g W^r H: every denominator is invertible
+        d[rq] = mul(a.n_field, sub(mul(a.shift_r[rq], wq), 1));
+        pre[rq] = run;
+        run = mul(run, d[rq]);
+    }
+    u64 iv = inv(run);
+    for (int rq = (int)Rq - 1; rq >= 0; rq--) {
+        out[(size_t)rq * n + q] = mul(a.zh[rq], mul(iv, pre[rq]));
+        iv = mul(iv, d[rq]);
+    }
+}
+// selector filter of one gate at one point: prod_{i in group, i != row} (i - s) [* (UNUSED - s)]
+__device__ __forceinline__ u64 gate_filter(const QArgs &a, const DevGate &g, size_t N, size_t slot) {
+    const u64 s = a.cs[(size_t)g.selector_index * N + slot];
+    u64 filter = 1;
+    for (u32 i = g.group_start; i < g.group_end; i++)
+        if (i != g.row) filter = mul(filter, sub((u64)i, s));
+    if (a.many_selectors) filter = mul(filter, sub(0xFFFFFFFFull, s));
+    return filter;
+}
+// The unfiltered constraints of one gate, multiplied into the carry-free accumulators ga[c] (+= constraint_k alpha_c^(k0 + k)).
+// HEAD_ONLY (the four base-4 limb gates of plonky2_u32): skip the limb columns -- their range products, base-4 sums and the
+// sum-equals-wire constraints -- which k_quotient_limbs evaluates for all fused gates from ONE read of the wire planes.
+template <int NCH, int TYPE, bool HEAD_ONLY = false>
+__device__ __forceinline__ void gate_terms(const QArgs &a, const DevGate &g, size_t N, size_t slot, u32 k0, AccLimb (&ga)[MAXCH]) {
     const u32 nt = a.nterms;
     const u64 *W = a.wl + slot;                       // wire j  -> W[j * N]
     const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
     {
-        const u64 s = a.cs[(size_t)g.selector_index * N + slot];
-        u64 filter = 1;
-        for (u32 i = g.group_start; i < g.group_end; i++)
-            if (i != g.row) filter = mul(filter, sub((u64)i, s));
-        if (a.many_selectors) filter = mul(filter, sub(0xFFFFFFFFull, s));
-        AccLimb ga[MAXCH];
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[c]);
         const u64 *ap = a.apow + k0;
 #define EMIT(k, v)                                                                     \
     do {                                                                               \
@@ -403,12 +426,14 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 const u64 hi_not_max = sub(mul(iv, sub(0xFFFFFFFFull, hi)), 1);
                 EMIT(k, mul_nc(hi_not_max, lo)); k++;
                 EMIT(k, sub(add(mul(hi, (u64)1 << 32), lo), add(mul(m0, m1), ad))); k++;
-                u64 cl = 0, chh = 0;
-                const u64 *limbs = W + (size_t)(6 * nops + 32 * i) * N;
-                LIMBS4_DESC(limbs, 32, 16, k + (31 - _j), cl, chh);
-                k += 32;
-                EMIT(k, sub(cl, lo)); k++;
-                EMIT(k, sub(chh, hi)); k++;
+                if constexpr (!HEAD_ONLY) {
+                    u64 cl = 0, chh = 0;
+                    const u64 *limbs = W + (size_t)(6 * nops + 32 * i) * N;
+                    LIMBS4_DESC(limbs, 32, 16, k + (31 - _j), cl, chh);
+                    EMIT(k + 32, sub(cl, lo));
+                    EMIT(k + 33, sub(chh, hi));
+                }
+                k += 34;
             }
             break;
         }
@@ -419,12 +444,14 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 for (u32 j = 0; j < na; j++) sum = add(sum, W[(size_t)(wd * i + j) * N]);
                 const u64 res = W[(size_t)(wd * i + na + 1) * N], car = W[(size_t)(wd * i + na + 2) * N];
                 EMIT(k, sub(add(mul(car, (u64)1 << 32), res), sum)); k++;
-                u64 cr = 0, cc = 0;
-                const u64 *limbs = W + (size_t)(wd * nops + 18 * i) * N;
-                LIMBS4_DESC(limbs, 18, 16, k + (17 - _j), cr, cc);
-                k += 18;
-                EMIT(k, sub(cr, res)); k++;
-                EMIT(k, sub(cc, car)); k++;
+                if constexpr (!HEAD_ONLY) {
+                    u64 cr = 0, cc = 0;
+                    const u64 *limbs = W + (size_t)(wd * nops + 18 * i) * N;
+                    LIMBS4_DESC(limbs, 18, 16, k + (17 - _j), cr, cc);
+                    EMIT(k + 18, sub(cr, res));
+                    EMIT(k + 19, sub(cc, car));
+                }
+                k += 20;
             }
             break;
         }
@@ -434,25 +461,29 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
                 const u64 xx = W[(size_t)(5 * i) * N], yy = W[(size_t)(5 * i + 1) * N], bi = W[(size_t)(5 * i + 2) * N];
                 const u64 res = W[(size_t)(5 * i + 3) * N], bo = W[(size_t)(5 * i + 4) * N];
                 EMIT(k, sub(res, add(sub(sub(xx, yy), bi), mul(bo, (u64)1 << 32)))); k++;
-                u64 cl = 0, unused_hi = 0;
-                const u64 *limbs = W + (size_t)(5 * nops + 16 * i) * N;
-                LIMBS4_DESC(limbs, 16, 16, k + (15 - _j), cl, unused_hi);
-                (void)unused_hi;
-                k += 16;
-                EMIT(k, sub(cl, res)); k++;
+                if constexpr (!HEAD_ONLY) {
+                    u64 cl = 0, unused_hi = 0;
+                    const u64 *limbs = W + (size_t)(5 * nops + 16 * i) * N;
+                    LIMBS4_DESC(limbs, 16, 16, k + (15 - _j), cl, unused_hi);
+                    (void)unused_hi;
+                    EMIT(k + 16, sub(cl, res));
+                }
+                k += 17;
                 EMIT(k, mul_nc(bo, sub(1, bo))); k++;
             }
             break;
         }
         case GLP_GATE_U32_RANGE_CHECK: {
             u32 k = 0; const u32 nin = g.p0;
-            for (u32 i = 0; i < nin; i++) {
-                const u64 *aux = W + (size_t)(nin + 16 * i) * N;
-                u64 sum = 0, unused_hi = 0;
-                LIMBS4_DESC(aux, 16, 16, k + 1 + _j, sum, unused_hi);
-                (void)unused_hi;
-                EMIT(k, sub(sum, W[(size_t)i * N]));
-                k += 17;
+            if constexpr (!HEAD_ONLY) {
+                for (u32 i = 0; i < nin; i++) {
+                    const u64 *aux = W + (size_t)(nin + 16 * i) * N;
+                    u64 sum = 0, unused_hi = 0;
+                    LIMBS4_DESC(aux, 16, 16, k + 1 + _j, sum, unused_hi);
+                    (void)unused_hi;
+                    EMIT(k, sub(sum, W[(size_t)i * N]));
+                    k += 17;
+                }
             }
             break;
         }
@@ -541,14 +572,44 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
         }
 #undef LIMBS4_DESC
 #undef EMIT
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[c])));
     }
 }
+// Contribution of ONE gate at one point: filter(selector) * sum_k constraint_k * alpha_c^(k0 + k), added into acc[c].
+// TYPE >= 0 compiles a single gate body (per-gate kernels: small register footprint, high occupancy); TYPE = -1
+// keeps the run-time switch (monolithic fallback).
+template <int NCH, int TYPE>
+__device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
+    const u64 filter = gate_filter(a, g, N, slot);
+    AccLimb ga[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[c]);
+    gate_terms<NCH, TYPE, false>(a, g, N, slot, k0, ga);
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[c])));
+}
 
+// Gates that ride along with another launch (indices into the gate table)
+struct LightArgs { u32 count; u32 gi[8]; };
+// The HBM-bound gate types (Constant, PublicInput, Arithmetic, BaseSum, RandomAccess), evaluated one after the other
+template <int NCH>
+__device__ __forceinline__ void light_gates(const QArgs &a, const LightArgs &la, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
+    for (u32 t = 0; t < la.count; t++) {
+        const DevGate g = a.gates[la.gi[t]];
+        switch (g.type) {                      // uniform: every lane runs the same gate
+        case GLP_GATE_CONSTANT: gate_contrib<NCH, GLP_GATE_CONSTANT>(a, g, N, slot, k0, acc); break;
+        case GLP_GATE_PUBLIC_INPUT: gate_contrib<NCH, GLP_GATE_PUBLIC_INPUT>(a, g, N, slot, k0, acc); break;
+        case GLP_GATE_ARITHMETIC: gate_contrib<NCH, GLP_GATE_ARITHMETIC>(a, g, N, slot, k0, acc); break;
+        case GLP_GATE_BASE_SUM: gate_contrib<NCH, GLP_GATE_BASE_SUM>(a, g, N, slot, k0, acc); break;
+        case GLP_GATE_RANDOM_ACCESS: gate_contrib<NCH, GLP_GATE_RANDOM_ACCESS>(a, g, N, slot, k0, acc); break;
+        default: break;
+        }
+    }
+}
 // K6: vanishing polynomial / Z_H on the planes r = 0, step, 2 step, ... of the coset-major LDE domain.
 //   terms: [L_0 (Z_c - 1)]_c, [prev*num - next*den]_{c,chunk}, gate constraints; res_c = sum_k term_k alpha_c^k
-template <int NCH, bool WITH_GATES>
-__global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
+// GATES: 0 = permutation terms only; 1 = every gate (monolithic, run-time switch); 2 = the light gates of `la`: the
+// permutation terms are VALU-bound and the light gates HBM-bound, so in one launch the waves in one phase fill the other
+// phase's idle unit (separately: 3.3 + 2.75 ms at the headline size)
+template <int NCH, int GATES>
+__global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, LightArgs la) {
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
@@ -559,7 +620,7 @@ __global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
     u64 acc[MAXCH], zx[MAXCH], zg[MAXCH];
     Acc160 pa[MAXCH];
     _Pragma("unroll") for (int c = 0; c < NCH; c++) { acc_zero(pa[c]); zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
-    const u64 l0 = mul(a.zh[rq], inv(mul(a.n_field, sub(x, 1))));
+    const u64 l0 = a.l0[(size_t)rq * n + q];
     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
         const u64 t = mul(l0, sub(zx[c], 1));
         _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + c]);
@@ -603,12 +664,13 @@ __global__ __launch_bounds__(256, WITH_GATES ? 3 : 4) void k_quotient(QArgs a) {
     }
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
     const u32 k0 = nch + nch * nchunks;
-    if constexpr (WITH_GATES) {                        // monolithic: every gate here
+    if constexpr (GATES == 1) {                        // monolithic: every gate here
         for (u32 gi = 0; gi < a.num_gates; gi++) {
             const DevGate g = a.gates[gi];
             gate_contrib<NCH, -1>(a, g, N, slot, k0, acc);
         }
     }
+    if constexpr (GATES == 2) light_gates<NCH>(a, la, N, slot, k0, acc);
     const size_t Rq = (size_t)gridDim.y;
     _Pragma("unroll") for (int c = 0; c < NCH; c++) a.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
 }
@@ -625,6 +687,100 @@ __global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, u32 gi) {
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
     const DevGate g = a.gates[gi];
     gate_contrib<NCH, TYPE>(a, g, N, slot, (u32)NCH + (u32)NCH * (a.npp + 1), acc);
+    const size_t Rq = (size_t)gridDim.y;
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) {
+        u64 *o = a.out + ((size_t)c * Rq + rq) * n + q;
+        *o = add(*o, mul(acc[c], a.zh_inv[rq]));
+    }
+}
+
+// The base-4 limb gates of plonky2_u32 (U32Arithmetic, U32AddMany, U32Subtraction, U32RangeCheck) in ONE launch.  Their
+// limb columns overlap almost completely (wires 30..113 are limbs of all four in the secp256k1 circuit): every wire plane
+// is read once, range_product(w_j, 4) is computed once per column and multiplied into each gate's own carry-free
+// accumulators (the selector filters are applied after the reduction, as in the per-gate kernels).  The per-column work
+// is driven by a table built at circuit creation (uniform control flow, scalar loads):
+//   desc[j][s] for wire column j and fused gate slot s:
+//     bit 0        the column is a base-4 limb of this gate
+//     bits 1..4    position of the limb in its base-4 sum (weight 4^pos)
+//     bit 5        this limb closes the sum: emit  (sum - W[ref])  at alpha index kf, then reset the sum
+//     bits 6..15   alpha index of the limb's range-check constraint
+//     bits 16..25  kf        bits 26..33  ref (wire column the sum must equal)
+// The constraints that are not limb work (two per U32Arithmetic op, one per AddMany op, two per Subtraction op) come from
+// gate_terms<.., HEAD_ONLY = true>.
+// `extra`: HBM-bound gates without limb work of their own kind (ComparisonGate) evaluated in the same launch, for the same
+// reason as the light gates in k_quotient: their loads overlap the limb gates' arithmetic.
+constexpr int LIMB_SLOTS = 4;
+struct LimbArgs { const u64 *desc; u32 count, jlo, jhi; u32 gi[LIMB_SLOTS]; u32 extra_count, extra_gi[4]; };
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, LimbArgs la) {
+    const size_t n = (size_t)1 << a.lg, N = n << a.rb;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const u32 rq = blockIdx.y, r = rq * a.step;
+    const size_t slot = (size_t)r * n + q;
+    const u32 k0 = (u32)NCH + (u32)NCH * (a.npp + 1), nt = a.nterms;
+    const u64 *W = a.wl + slot;
+    const u64 *ap = a.apow + k0;
+    AccLimb ga[LIMB_SLOTS][MAXCH];
+    Base4Sum bs[LIMB_SLOTS];
+    _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+        b4_zero(bs[s]);
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[s][c]);
+    }
+    // heads
+    _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+        if ((u32)s < la.count) {
+            const DevGate g = a.gates[la.gi[s]];
+            switch (g.type) {
+            case GLP_GATE_U32_ARITHMETIC: gate_terms<NCH, GLP_GATE_U32_ARITHMETIC, true>(a, g, N, slot, k0, ga[s]); break;
+            case GLP_GATE_U32_ADD_MANY: gate_terms<NCH, GLP_GATE_U32_ADD_MANY, true>(a, g, N, slot, k0, ga[s]); break;
+            case GLP_GATE_U32_SUBTRACTION: gate_terms<NCH, GLP_GATE_U32_SUBTRACTION, true>(a, g, N, slot, k0, ga[s]); break;
+            default: break;                    // U32RangeCheck: limb work only
+            }
+        }
+    }
+#define LIMB_EMIT(S, K, V)                                                                                     \
+    do {                                                                                                       \
+        const u64 _v = (V);                                                                                    \
+        const u32 _v0 = (u32)_v & 0x3FFFFFu, _v1 = (u32)(_v >> 22) & 0x3FFFFFu, _v2 = (u32)(_v >> 44);         \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(ga[S][c2], _v0, _v1, _v2, ap[c2 * nt + (K)]);   \
+    } while (0)
+    for (u32 j0 = la.jlo; j0 <= la.jhi; j0 += 8) {
+        u64 lv[8];
+        _Pragma("unroll") for (int t = 0; t < 8; t++) if (j0 + t <= la.jhi) lv[t] = W[(size_t)(j0 + t) * N];
+        _Pragma("unroll") for (int t = 0; t < 8; t++) if (j0 + t <= la.jhi) {
+            const u64 v = lv[t];
+            const u64 *dj = la.desc + (size_t)(j0 + t) * LIMB_SLOTS;
+            const u64 rp = range_product(v, 4);
+            const u32 r0 = (u32)rp & 0x3FFFFFu, r1 = (u32)(rp >> 22) & 0x3FFFFFu, r2 = (u32)(rp >> 44);
+            _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+                const u64 d = dj[s];
+                if (d & 1) {
+                    const u32 kl = (u32)(d >> 6) & 0x3FFu;
+                    _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(ga[s][c2], r0, r1, r2, ap[c2 * nt + kl]);
+                    b4_add(bs[s], v, (u32)(d >> 1) & 15u);
+                    if (d & 32) {
+                        const u32 kf = (u32)(d >> 16) & 0x3FFu, ref = (u32)(d >> 26) & 0xFFu;
+                        LIMB_EMIT(s, kf, sub(b4_value(bs[s]), W[(size_t)ref * N]));
+                        b4_zero(bs[s]);
+                    }
+                }
+            }
+        }
+    }
+#undef LIMB_EMIT
+    u64 acc[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
+    _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+        if ((u32)s < la.count) {
+            const u64 filter = gate_filter(a, a.gates[la.gi[s]], N, slot);
+            _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[s][c])));
+        }
+    }
+    for (u32 t = 0; t < la.extra_count; t++) {             // after the limb accumulators are dead (register budget)
+        const DevGate g = a.gates[la.extra_gi[t]];
+        if (g.type == GLP_GATE_COMPARISON) gate_contrib<NCH, GLP_GATE_COMPARISON>(a, g, N, slot, k0, acc);
+    }
     const size_t Rq = (size_t)gridDim.y;
     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
         u64 *o = a.out + ((size_t)c * Rq + rq) * n + q;
@@ -1022,15 +1178,35 @@ struct glp_session {
             // two challenges (every preset the reference uses): permutation terms in one launch, then one launch per
             // gate type compiled on its own; other challenge counts take the monolithic kernel
             a.gate_mode = nch == 2 ? 1 : 0;
+            u64 *l0t;
+            GLP_TRY(tmp.get(&l0t, (size_t)Rq * n));
+            a.l0 = l0t;
+            hipLaunchKernelGGL(k_l0_table, dim3(nblk(n)), dim3(256), 0, c->stream, a, l0t, Rq);
+            GLP_HIP(hipGetLastError());
+            LightArgs lg_;
+            lg_.count = cc->light_count;
+            for (u32 i = 0; i < 8; i++) lg_.gi[i] = cc->light_gi[i];
             switch (nch) {
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1, true>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
-            case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, false>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
-            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3, true>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4, true>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a); break;
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_); break;
+            case 2:
+                if (cc->light_count) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 0>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_);
+                break;
+            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_); break;
             }
             GLP_HIP(hipGetLastError());
             if (a.gate_mode == 1) {
-                for (u32 gi = 0; gi < d.num_gates; gi++) {
+                if (cc->limb_count) {
+                    LimbArgs la;
+                    la.desc = cc->dev_limb_desc; la.count = cc->limb_count; la.jlo = cc->limb_jlo; la.jhi = cc->limb_jhi;
+                    for (int i = 0; i < LIMB_SLOTS; i++) la.gi[i] = cc->limb_gi[i];
+                    la.extra_count = cc->limb_extra_count;
+                    for (int i = 0; i < 4; i++) la.extra_gi[i] = cc->limb_extra_gi[i];
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_limbs<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, la);
+                    GLP_HIP(hipGetLastError());
+                }
+                for (u32 gi : cc->single_gates) {
 #define GLP_GATE_LAUNCH(T) case T: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_gate<2, T>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, gi); break;
                     switch (cc->gates[gi].type) {
                         GLP_GATE_LAUNCH(GLP_GATE_CONSTANT) GLP_GATE_LAUNCH(GLP_GATE_PUBLIC_INPUT) GLP_GATE_LAUNCH(GLP_GATE_ARITHMETIC)
@@ -1352,6 +1528,72 @@ template <class F> void walk_proof(const glp_circuit *cc, F f) {
 }  // namespace
 
 
+// Quotient launch plan: the base-4 limb gates (at most LIMB_SLOTS of them) share k_quotient_limbs, the HBM-bound light
+// gates share k_quotient_light, every other gate type keeps its own launch.  Builds the column program of
+// k_quotient_limbs (format: see the kernel).
+static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
+    const glp_circuit_desc &d = cc->d;
+    std::vector<u64> desc((size_t)d.num_wires * LIMB_SLOTS, 0);
+    u32 jlo = d.num_wires, jhi = 0;
+    auto put = [&](u32 slot, u32 col, u32 pos, u32 kl, bool flush, u32 kf, u32 ref) {
+        desc[(size_t)col * LIMB_SLOTS + slot] = 1ull | ((u64)pos << 1) | (flush ? 32ull : 0ull) | ((u64)kl << 6) | ((u64)kf << 16) | ((u64)ref << 26);
+        jlo = std::min(jlo, col); jhi = std::max(jhi, col);
+    };
+    for (u32 gi = 0; gi < d.num_gates; gi++) {
+        const glp_gate &g = cc->gates[gi];
+        const bool limb_gate = g.type == GLP_GATE_U32_ARITHMETIC || g.type == GLP_GATE_U32_ADD_MANY ||
+                               g.type == GLP_GATE_U32_SUBTRACTION || g.type == GLP_GATE_U32_RANGE_CHECK;
+        const bool light = g.type == GLP_GATE_CONSTANT || g.type == GLP_GATE_PUBLIC_INPUT || g.type == GLP_GATE_ARITHMETIC ||
+                           g.type == GLP_GATE_BASE_SUM || g.type == GLP_GATE_RANDOM_ACCESS;
+        // alpha indices and wire columns must fit the descriptor fields (10 and 8 bits); glp_circuit_create has already
+        // bounded num_constraints by ACC_MAX_TERMS = 1024
+        if (limb_gate && cc->limb_count < (u32)LIMB_SLOTS && d.num_wires <= 256) {
+            const u32 s = cc->limb_count++;
+            cc->limb_gi[s] = gi;
+            if (g.type == GLP_GATE_U32_ARITHMETIC) {
+                for (u32 i = 0; i < g.p0; i++)
+                    for (u32 j = 0; j < 32; j++)
+                        put(s, 6 * g.p0 + 32 * i + j, j & 15, 36 * i + 2 + (31 - j), (j & 15) == 15, 36 * i + 34 + (j >> 4), 6 * i + 3 + (j >> 4));
+            } else if (g.type == GLP_GATE_U32_ADD_MANY) {
+                const u32 na = g.p0, nops = g.p1, wd = na + 3;
+                for (u32 i = 0; i < nops; i++)
+                    for (u32 j = 0; j < 18; j++)
+                        put(s, wd * nops + 18 * i + j, j & 15, 21 * i + 1 + (17 - j), j == 15 || j == 17, 21 * i + 19 + (j >> 4), wd * i + na + 1 + (j >> 4));
+            } else if (g.type == GLP_GATE_U32_SUBTRACTION) {
+                for (u32 i = 0; i < g.p0; i++)
+                    for (u32 j = 0; j < 16; j++)
+                        put(s, 5 * g.p0 + 16 * i + j, j, 19 * i + 1 + (15 - j), j == 15, 19 * i + 17, 5 * i + 3);
+            } else {
+                for (u32 i = 0; i < g.p0; i++)
+                    for (u32 j = 0; j < 16; j++)
+                        put(s, g.p0 + 16 * i + j, j, 17 * i + 1 + j, j == 15, 17 * i, i);
+            }
+        } else if (light && cc->light_count < 8) {
+            cc->light_gi[cc->light_count++] = gi;
+        } else if (g.type != GLP_GATE_NOOP) {
+            cc->single_gates.push_back(gi);
+        }
+    }
+    if (cc->limb_count == 1) {                 // nothing to share: the gate's own kernel is the better launch
+        cc->single_gates.push_back(cc->limb_gi[0]);
+        cc->limb_count = 0;
+    }
+    if (cc->limb_count) {                      // ComparisonGate (HBM-bound) rides with the VALU-bound limb launch
+        std::vector<u32> keep;
+        for (u32 gi : cc->single_gates) {
+            if (cc->gates[gi].type == GLP_GATE_COMPARISON && cc->limb_extra_count < 4) cc->limb_extra_gi[cc->limb_extra_count++] = gi;
+            else keep.push_back(gi);
+        }
+        cc->single_gates.swap(keep);
+    }
+    if (cc->limb_count) {
+        cc->limb_jlo = jlo; cc->limb_jhi = jhi;
+        GLP_TRY(c->alloc((void **)&cc->dev_limb_desc, desc.size() * 8));
+        GLP_TRY(h2d(c, cc->dev_limb_desc, desc.data(), desc.size() * 8));
+    }
+    return GLP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -1364,6 +1606,7 @@ void glp_circuit_free(glp_circuit *cc) {
     c->release(cc->dev_sigmas);
     c->release(cc->dev_k_is);
     c->release(cc->dev_gates);
+    c->release(cc->dev_limb_desc);
     delete cc;
 }
 
@@ -1474,6 +1717,7 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
     GLP_TRY(h2d(c, cc->dev_gates, cc->gates.data(), sizeof(DevGate) * d.num_gates));
     GLP_TRY(h2d(c, cc->dev_k_is, cc->k_is.data(), (size_t)nr * 8));
     GLP_TRY(h2d(c, cc->dev_sigmas, d.sigmas, (size_t)nr * n * 8));
+    GLP_TRY(build_quotient_plan(c, cc.get()));
     {
         void *v = nullptr;
         GLP_TRY(c->alloc(&v, (size_t)(nc + nr) * n * 8));

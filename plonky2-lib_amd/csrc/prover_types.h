@@ -31,6 +31,12 @@ struct glp_circuit {
     u64 *dev_k_is = nullptr;
     u32 k_ratio = 0;               // g if k_is[j] = g^j for all j with g < 2^32 (then the quotient kernel chains by g), else 0
     u64 *dev_sigmas = nullptr;     // [nr][n] values on H (natural order), for the partial products
+    // quotient launch plan (built once in glp_circuit_create): which gates share a launch
+    u64 *dev_limb_desc = nullptr;  // [num_wires][4] column program of k_quotient_limbs
+    u32 limb_count = 0, limb_gi[4] = {0, 0, 0, 0}, limb_jlo = 0, limb_jhi = 0;
+    u32 limb_extra_count = 0, limb_extra_gi[4] = {0, 0, 0, 0};
+    u32 light_count = 0, light_gi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<u32> single_gates; // gates that keep a launch of their own
     glp_batch *cs = nullptr;       // constants_sigmas_commitment
     std::vector<u64> cs_cap;
     Layout L;

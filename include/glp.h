@@ -201,6 +201,26 @@ GLP_API int glp_prove(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *
 GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *dev_wires,
                              const uint64_t *public_inputs, uint64_t *proof_out);
 
+/* ---- witness generation, the row-local half ------------------------------------------
+ * plonky2 `iop/generator.rs::generate_partial_witness` interleaves two kinds of work: the copy-constraint dataflow
+ * between rows (stays with the reference's CPU gadget code) and the row-local `SimpleGenerator`s that derive the rest
+ * of a row from that row's own inputs.  glp_witness_fill applies every row-local generator of the gate library once,
+ * one GPU thread per trace row, in place on an HBM-resident witness [num_wires][n]:
+ *   the reference's own generators  U32InterleaveGenerator [REF src/u32/gates/interleave_u32.rs:289-318],
+ *     UninterleaveToU32Generator [REF src/u32/gates/uninterleave_to_u32.rs:332-369], UninterleaveToB32Generator
+ *     [REF src/u32/gates/uninterleave_to_b32.rs:335-372];
+ *   plonky2_u32 (recalled) U32Arithmetic / U32AddMany / U32Subtraction / U32RangeCheck / Comparison generators;
+ *   plonky2 (recalled)     BaseSplitGenerator, ArithmeticBaseGenerator, RandomAccessGenerator, PoseidonGenerator,
+ *                          ConstantGenerator.
+ * Each generator reads its dependencies (glp_witness_columns role 2) from the row and writes its outputs (role 1):
+ * bits, base-4 limbs, inverses, S-box traces, u32 results.  only_advice != 0: only non-routed columns
+ * (index >= num_routed_wires) are written, for a caller whose CPU pass already resolved every routed wire -- then the
+ * GPU derives the 56 limb columns of the secp256k1 trace (41 % of the witness) and they never cross PCIe.
+ * The row's gate is read from the circuit's selector polynomials.  Asynchronous on the ctx stream. */
+GLP_API int glp_witness_fill(glp_ctx *ctx, const glp_circuit *circuit, uint64_t *dev_wires, int only_advice);
+/* role_out[col] for rows of gate `gate_index`: 1 = written by glp_witness_fill, 2 = read as a generator input, 0 = untouched */
+GLP_API int glp_witness_columns(const glp_circuit *circuit, uint32_t gate_index, uint8_t *role_out /* [num_wires] */);
+
 /* ---- the same proof, stepped by the caller's own transcript -------------------------------------------------
  * `prove_with_partition_witness` is Fiat-Shamir glue around six device stages.  A Rust integration that keeps
  * plonky2's own `Challenger` (so that the transcript is the fork's by construction) calls the stages one by one:

@@ -303,6 +303,12 @@ class OracleCircuit:
         rc = lib().glo_prove(C.byref(self.s), _p(w), _p(pi) if pi.size else None, _p(proof))
         return rc, proof
 
+    def witness_fill(self, wires, only_advice=False):
+        """gl_witness_oracle.c: every row-local generator once, on a copy of `wires` [num_wires][n]."""
+        w = _a(wires).copy()
+        lib().glo_witness_fill(C.byref(self.s), _p(w), C.c_int(1 if only_advice else 0))
+        return w
+
     def verify(self, proof):
         return lib().glo_verify(C.byref(self.s), _p(self.cs_cap), _p(_a(proof)))
 

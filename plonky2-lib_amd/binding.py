@@ -126,6 +126,8 @@ def load_library():
         "glp_session_end": [vp],
         "glp_verify": [vp, vp],
         "glp_verify_n": [vp, vp, sz],
+        "glp_witness_fill": [vp, vp, vp, C.c_int],
+        "glp_witness_columns": [vp, u32, vp],
         "glp_dev_alloc": [vp, sz, C.POINTER(vp)],
         "glp_dev_free": [vp, vp],
         "glp_dev_upload": [vp, vp, vp, sz],
@@ -453,6 +455,16 @@ class Circuit:
         words = np.zeros(self.proof_words, np.uint64)
         _chk(load_library().glp_proof_from_bytes(self._h, buf.ctypes.data_as(C.c_void_p), buf.size, _p(words)))
         return words
+
+    def witness_fill(self, dev_wires_ptr, only_advice=False):
+        """Row-local witness generation in place on an HBM-resident witness (include/glp.h, glp_witness_fill)."""
+        _chk(load_library().glp_witness_fill(self.ctx._h, self._h, C.c_void_p(dev_wires_ptr), 1 if only_advice else 0))
+
+    def witness_columns(self, gate_index):
+        """uint8 [num_wires]: 1 = written by witness_fill on rows of that gate, 2 = read as generator input, 0 = untouched."""
+        out = np.zeros(int(self.desc.num_wires), np.uint8)
+        _chk(load_library().glp_witness_columns(self._h, int(gate_index), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def prove_device(self, dev_wires_ptr, public_inputs=None):
         pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)

@@ -1607,6 +1607,7 @@ void glp_circuit_free(glp_circuit *cc) {
     c->release(cc->dev_k_is);
     c->release(cc->dev_gates);
     c->release(cc->dev_limb_desc);
+    c->release(cc->dev_consts);
     delete cc;
 }
 
@@ -1717,12 +1718,18 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
     GLP_TRY(h2d(c, cc->dev_gates, cc->gates.data(), sizeof(DevGate) * d.num_gates));
     GLP_TRY(h2d(c, cc->dev_k_is, cc->k_is.data(), (size_t)nr * 8));
     GLP_TRY(h2d(c, cc->dev_sigmas, d.sigmas, (size_t)nr * n * 8));
+    GLP_TRY(c->alloc((void **)&cc->dev_consts, (size_t)nc * n * 8));
+    GLP_TRY(h2d(c, cc->dev_consts, d.constants, (size_t)nc * n * 8));
     GLP_TRY(build_quotient_plan(c, cc.get()));
     {
         void *v = nullptr;
         GLP_TRY(c->alloc(&v, (size_t)(nc + nr) * n * 8));
         u64 *csv = (u64 *)v;
-        int rc = h2d(c, csv, d.constants, (size_t)nc * n * 8);
+        int rc = GLP_OK;
+        {
+            hipError_t e = hipMemcpyAsync(csv, cc->dev_consts, (size_t)nc * n * 8, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "D2D copy: %s", hipGetErrorString(e));
+        }
         if (rc == GLP_OK) {
             hipError_t e = hipMemcpyAsync(csv + (size_t)nc * n, cc->dev_sigmas, (size_t)nr * n * 8, hipMemcpyDeviceToDevice, c->stream);
             if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "D2D copy: %s", hipGetErrorString(e));

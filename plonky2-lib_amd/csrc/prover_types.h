@@ -31,6 +31,7 @@ struct glp_circuit {
     u64 *dev_k_is = nullptr;
     u32 k_ratio = 0;               // g if k_is[j] = g^j for all j with g < 2^32 (then the quotient kernel chains by g), else 0
     u64 *dev_sigmas = nullptr;     // [nr][n] values on H (natural order), for the partial products
+    u64 *dev_consts = nullptr;     // [nc][n] values on H (selectors first): which gate sits on a row (witness.hip)
     // quotient launch plan (built once in glp_circuit_create): which gates share a launch
     u64 *dev_limb_desc = nullptr;  // [num_wires][4] column program of k_quotient_limbs
     u32 limb_count = 0, limb_gi[4] = {0, 0, 0, 0}, limb_jlo = 0, limb_jhi = 0;

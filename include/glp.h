@@ -183,6 +183,24 @@ GLP_API int glp_circuit_constants_sigmas_cap(const glp_circuit *circuit, uint64_
 /* Number of uint64_t words of a proof of this circuit (layout below). */
 GLP_API size_t glp_proof_words(const glp_circuit *circuit);
 
+/* ---- circuit hand-off file --------------------------------------------------------------
+ * The reference persists circuits with `CircuitData::to_bytes(&gate_serializer, &generator_serializer)` and reloads them
+ * with `from_bytes` [REF src/ecdsa/gadgets/ecdsa.rs:298-316; serializer tables REF src/ecdsa/gadgets/ecdsa.rs:68-135,
+ * src/ecdsa/serialization.rs:7-46].  That byte layout belongs to the absent plonky2 crate and carries the generator list,
+ * which the GPU prover does not need.  The file below is this library's own flat dump of glp_circuit_desc (+ optionally one
+ * witness and its public inputs): versioned header, little-endian sections, FNV-1a checksum; the exact layout is at the top
+ * of plonky2-lib_amd/csrc/circuit_file.hip, the Rust writer that fills it from `data.common` / `data.prover_only` is in
+ * INTEGRATION.md.  Host-only calls (no GPU needed); glp_circuit_file_open maps the file (GB-sized circuits are not copied)
+ * and the descriptor's pointers stay valid until glp_circuit_file_close. */
+typedef struct glp_circuit_file glp_circuit_file;
+GLP_API int glp_circuit_file_write(const char *path, const glp_circuit_desc *desc, const uint64_t *wires /* [num_wires][n] or NULL */,
+                                   const uint64_t *public_inputs /* [num_public_inputs], with wires */);
+GLP_API int glp_circuit_file_open(const char *path, int verify_checksum, glp_circuit_file **out);
+GLP_API void glp_circuit_file_close(glp_circuit_file *file);
+GLP_API const glp_circuit_desc *glp_circuit_file_desc(const glp_circuit_file *file);       /* feed to glp_circuit_create */
+GLP_API const uint64_t *glp_circuit_file_wires(const glp_circuit_file *file);              /* NULL if the file has no witness */
+GLP_API const uint64_t *glp_circuit_file_public_inputs(const glp_circuit_file *file);
+
 /* `CircuitData::prove` after witness generation (plonk/prover.rs `prove_with_partition_witness`,
  * steps "compute wires commitment" .. "compute opening proofs").
  *   wires          [num_wires][n] full witness (`witness.wire_values`), host or (…_device) HBM resident

@@ -133,6 +133,16 @@ def load_library():
         "glp_dev_upload": [vp, vp, vp, sz],
         "glp_dev_download": [vp, vp, vp, sz],
     })
+    sigs.update({
+        "glp_circuit_file_write": [C.c_char_p, C.POINTER(_CircuitDesc), vp, vp],
+        "glp_circuit_file_open": [C.c_char_p, C.c_int, C.POINTER(vp)],
+        "glp_circuit_file_close": [vp],
+    })
+    L.glp_circuit_file_desc.restype = C.POINTER(_CircuitDesc)
+    L.glp_circuit_file_desc.argtypes = [vp]
+    for name in ("glp_circuit_file_wires", "glp_circuit_file_public_inputs"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
     for name in ("glp_num_openings", "glp_final_poly_len"):
         getattr(L, name).restype = sz
         getattr(L, name).argtypes = [vp]
@@ -142,6 +152,7 @@ def load_library():
     L.glp_batch_free.restype = None
     L.glp_circuit_free.restype = None
     L.glp_session_end.restype = None
+    L.glp_circuit_file_close.restype = None
     _lib = L
     return L
 
@@ -344,6 +355,113 @@ class Batch:
         return out
 
 
+def _desc_to_c(desc):
+    """synth.Circuit-like attribute bag -> (glp_circuit_desc, objects that must stay alive while it is used)."""
+    gates = (_Gate * len(desc.gates))()
+    for i, g in enumerate(desc.gates):
+        for f, _ in _Gate._fields_:
+            setattr(gates[i], f, int(g[f]))
+    k, const, sig = _a(desc.k_is), _a(desc.constants), _a(desc.sigmas)
+    # the C ABI takes bare pointers: every array's size is checked here so that a wrong shape is a GlpError, not a
+    # host over-read
+    n = 1 << int(desc.degree_bits)
+    if k.size != int(desc.num_routed_wires):
+        raise GlpError(-1, "k_is has %d entries, num_routed_wires is %d" % (k.size, desc.num_routed_wires))
+    if const.size != int(desc.num_constants) * n:
+        raise GlpError(-1, "constants has %d elements, expected num_constants * 2^degree_bits = %d" % (const.size, int(desc.num_constants) * n))
+    if sig.size != int(desc.num_routed_wires) * n:
+        raise GlpError(-1, "sigmas has %d elements, expected num_routed_wires * 2^degree_bits = %d" % (sig.size, int(desc.num_routed_wires) * n))
+    if len(desc.reduction_arity_bits) > 16:
+        raise GlpError(-1, "more than 16 FRI reductions")
+    d = _CircuitDesc()
+    for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
+              "quotient_degree_factor", "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
+              "proof_of_work_bits", "num_query_rounds"):
+        setattr(d, f, int(getattr(desc, f)))
+    d.num_reductions = len(desc.reduction_arity_bits)
+    for i, ab in enumerate(desc.reduction_arity_bits):
+        d.reduction_arity_bits[i] = int(ab)
+    d.num_gates, d.num_public_inputs = len(desc.gates), int(len(desc.public_inputs))
+    d.gates = C.cast(gates, C.POINTER(_Gate))
+    d.k_is, d.constants, d.sigmas = k.ctypes.data, const.ctypes.data, sig.ctypes.data
+    dig = getattr(desc, "circuit_digest", None)
+    if dig is not None:
+        for i in range(4):
+            d.circuit_digest[i] = int(dig[i])
+    return d, (gates, k, const, sig)
+
+
+def write_circuit_file(path, desc, with_witness=True):
+    """glp_circuit_file_write: the hand-off file a machine with the Rust builder produces (include/glp.h)."""
+    d, keep = _desc_to_c(desc)
+    w = pi = None
+    if with_witness:
+        w, pi = _a(desc.wires), _a(desc.public_inputs)
+        if w.size != int(desc.num_wires) << int(desc.degree_bits):
+            raise GlpError(-1, "wires has %d elements, expected num_wires * 2^degree_bits" % w.size)
+    _chk(load_library().glp_circuit_file_write(os.fsencode(path), C.byref(d), _p(w) if w is not None else None,
+                                               _p(pi) if (pi is not None and pi.size) else None))
+    del keep
+
+
+class _FileDesc:
+    pass
+
+
+class CircuitFile:
+    """A mapped circuit hand-off file; `.desc` is an attribute bag `Circuit(ctx, cf.desc)` accepts (numpy views into the
+    mapping, valid until close())."""
+
+    def __init__(self, path, verify_checksum=True):
+        L = load_library()
+        self._h = C.c_void_p()
+        _chk(L.glp_circuit_file_open(os.fsencode(path), 1 if verify_checksum else 0, C.byref(self._h)))
+        cd = L.glp_circuit_file_desc(self._h).contents
+        d = _FileDesc()
+        for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
+                  "quotient_degree_factor", "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
+                  "proof_of_work_bits", "num_query_rounds"):
+            setattr(d, f, int(getattr(cd, f)))
+        d.reduction_arity_bits = [int(cd.reduction_arity_bits[i]) for i in range(cd.num_reductions)]
+        d.gates = [{f: int(getattr(cd.gates[i], f)) for f, _ in _Gate._fields_} for i in range(cd.num_gates)]
+        n = 1 << d.degree_bits
+
+        def view(ptr, shape):
+            cnt = int(np.prod(shape))
+            if not ptr or cnt == 0:
+                return np.zeros(shape, np.uint64)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(cnt,)).reshape(shape)
+        d.k_is = view(cd.k_is, (d.num_routed_wires,))
+        d.constants = view(cd.constants, (d.num_constants, n))
+        d.sigmas = view(cd.sigmas, (d.num_routed_wires, n))
+        dig = [int(cd.circuit_digest[i]) for i in range(4)]
+        d.circuit_digest = np.array(dig, np.uint64) if any(dig) else None
+        wp = L.glp_circuit_file_wires(self._h)
+        self.has_witness = bool(wp)
+        d.wires = view(wp, (d.num_wires, n)) if wp else None
+        d.public_inputs = view(L.glp_circuit_file_public_inputs(self._h), (int(cd.num_public_inputs),)) if wp else \
+            np.zeros(int(cd.num_public_inputs), np.uint64)
+        self.desc = d
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.desc = None
+            load_library().glp_circuit_file_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Circuit:
     """Device-resident circuit data: what `builder.build::<C>()` hands the prover
     [REF src/ecdsa/gadgets/ecdsa.rs:298].  `desc` is an attribute bag like synth.Circuit."""
@@ -351,41 +469,13 @@ class Circuit:
     def __init__(self, ctx, desc):
         L = load_library()
         self.ctx, self.desc = ctx, desc
-        gates = (_Gate * len(desc.gates))()
-        for i, g in enumerate(desc.gates):
-            for f, _ in _Gate._fields_:
-                setattr(gates[i], f, int(g[f]))
-        k, const, sig = _a(desc.k_is), _a(desc.constants), _a(desc.sigmas)
-        # the C ABI takes bare pointers: every array's size is checked here so that a wrong shape is a GlpError, not a
-        # host over-read
+        d, keep = _desc_to_c(desc)
         n = 1 << int(desc.degree_bits)
-        if k.size != int(desc.num_routed_wires):
-            raise GlpError(-1, "k_is has %d entries, num_routed_wires is %d" % (k.size, desc.num_routed_wires))
-        if const.size != int(desc.num_constants) * n:
-            raise GlpError(-1, "constants has %d elements, expected num_constants * 2^degree_bits = %d" % (const.size, int(desc.num_constants) * n))
-        if sig.size != int(desc.num_routed_wires) * n:
-            raise GlpError(-1, "sigmas has %d elements, expected num_routed_wires * 2^degree_bits = %d" % (sig.size, int(desc.num_routed_wires) * n))
-        if len(desc.reduction_arity_bits) > 16:
-            raise GlpError(-1, "more than 16 FRI reductions")
         self._wire_elems = int(desc.num_wires) * n
         self._num_pis = int(len(desc.public_inputs))
-        d = _CircuitDesc()
-        for f in ("degree_bits", "num_wires", "num_routed_wires", "num_constants", "num_selectors", "num_challenges",
-                  "quotient_degree_factor", "num_partial_products", "num_gate_constraints", "rate_bits", "cap_height",
-                  "proof_of_work_bits", "num_query_rounds"):
-            setattr(d, f, int(getattr(desc, f)))
-        d.num_reductions = len(desc.reduction_arity_bits)
-        for i, ab in enumerate(desc.reduction_arity_bits):
-            d.reduction_arity_bits[i] = int(ab)
-        d.num_gates, d.num_public_inputs = len(desc.gates), int(len(desc.public_inputs))
-        d.gates = C.cast(gates, C.POINTER(_Gate))
-        d.k_is, d.constants, d.sigmas = k.ctypes.data, const.ctypes.data, sig.ctypes.data
-        dig = getattr(desc, "circuit_digest", None)
-        if dig is not None:
-            for i in range(4):
-                d.circuit_digest[i] = int(dig[i])
         self._h = C.c_void_p()
         _chk(L.glp_circuit_create(ctx._h, C.byref(d), C.byref(self._h)))
+        del keep
         self.proof_words = L.glp_proof_words(self._h)
 
     def free(self):

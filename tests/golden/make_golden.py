@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/*.npz from the CPU oracle (seeded).  The oracle itself is pinned by the
+"""Regenerates tests/golden/*.npz from the CPU oracle (seeded) and the sample circuit hand-off file zkdsa_2_3.glpc.  The oracle itself is pinned by the
 reference's Poseidon known-answer vector; see tests/test_oracle_poseidon.py."""
 import os
 import sys
@@ -28,6 +28,10 @@ def main():
     assert rc == 0 and oc.verify(proof) == 0
     np.savez_compressed(os.path.join(HERE, "proof_zkdsa_2_3.npz"), proof=proof, circuit_digest=np.asarray(desc.circuit_digest, np.uint64),
                         constants_sigmas_cap=oc.cs_cap, public_inputs=np.asarray(desc.public_inputs, np.uint64))
+    # the same circuit + witness as a circuit hand-off file (include/glp.h, glp_circuit_file_*): what a machine with the Rust
+    # builder would ship to the GPU box.  Written by the PRODUCT library's writer (host code, no GPU needed).
+    import plonky2_lib_amd as glp
+    glp.write_circuit_file(os.path.join(HERE, "zkdsa_2_3.glpc"), desc, with_witness=True)
 
 
 if __name__ == "__main__":

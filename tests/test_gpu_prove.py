@@ -404,6 +404,31 @@ def test_golden_proof_fixture(ctx):
     assert gc.verify(g["proof"])
 
 
+def test_circuit_file_to_proof(ctx, tmp_path):
+    """The hand-off path end to end, no oracle in the loop: the committed sample file (circuit + witness, as a Rust machine
+    would ship them) -> glp_circuit_create -> glp_prove reproduces the committed proof word for word; a file written from a
+    larger synthetic circuit proves identically to the in-process descriptor."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "proof_zkdsa_2_3.npz"))
+    with glp.CircuitFile(os.path.join(os.path.dirname(__file__), "golden", "zkdsa_2_3.glpc")) as cf:
+        gc = glp.Circuit(ctx, cf.desc)
+        assert (gc.digest() == g["circuit_digest"]).all()
+        proof = gc.prove(wires=cf.desc.wires, public_inputs=cf.desc.public_inputs)
+        assert (proof == g["proof"]).all() and gc.verify(proof)
+        gc.free()
+    desc = synth.ecdsa_shape_circuit(10, seed=33)
+    ref = glp.Circuit(ctx, desc)
+    want = ref.prove()
+    path = str(tmp_path / "ecdsa10.glpc")
+    glp.write_circuit_file(path, desc)
+    with glp.CircuitFile(path) as cf:
+        gc = glp.Circuit(ctx, cf.desc)
+        assert (gc.digest() == ref.digest()).all()
+        assert (gc.prove(wires=cf.desc.wires, public_inputs=cf.desc.public_inputs) == want).all()
+        gc.free()
+    ref.free()
+
+
 def test_verifier_rejects_tampered_proofs(ctx, oracle):
     """glp_verify (host-side restatement of plonk/verifier.rs + fri/verifier.rs, independent of the oracle) must reject a
     proof with any single word changed, section by section, and agree with the oracle's verifier on each."""

@@ -39,7 +39,9 @@ def parse():
                     help="ecdsa: the headline 2^20-row proof (default); zkdsa-batch: BASELINE config 5, a batch of independent "
                          "simple-signature proofs sharded over the ranks")
     ap.add_argument("--batch", type=int, default=256, help="zkdsa-batch: proofs in the whole batch")
-    ap.add_argument("--threads", type=int, default=4, help="zkdsa-batch: host threads (contexts/streams) per GPU")
+    ap.add_argument("--threads", type=int, default=2, help="zkdsa-batch: sub-batches in flight per GPU (own context / stream / host thread each)")
+    ap.add_argument("--sub-batch", type=int, default=128, help="zkdsa-batch: proofs per glp_prove_batch call")
+    ap.add_argument("--per-proof", action="store_true", help="zkdsa-batch: one glp_prove call per proof (the round-1 path), for comparison")
     ap.add_argument("--inflight", type=int, default=1,
                     help="ecdsa: independent proofs proved concurrently per GPU (own context/stream/host thread each); a step is "
                          "then a batch of that many proofs.  Default 1 keeps the per-stage timings free of overlap")
@@ -189,24 +191,38 @@ def spawn_ranks(a):
 
 
 def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
-    """BASELINE config 5: `--batch` independent simple-signature proofs [REF src/zkdsa/circuits/mod.rs:24-43], sharded
-    contiguously over the ranks (no collective); inside a rank, `--threads` host threads each own a context (= a HIP
-    stream) so that the latency-bound 2^3-row proofs overlap.  One step = the whole batch."""
+    """BASELINE config 5: `--batch` independent simple-signature proofs [REF src/zkdsa/circuits/mod.rs:24-43,322-339], sharded
+    contiguously over the ranks (no collective).  One step = the whole batch.  Inside a rank the shard goes through
+    glp_prove_batch in sub-batches of `--sub-batch` proofs (every device stage one launch over the sub-batch, the transcripts
+    on host threads), `--threads` sub-batches in flight on their own contexts (streams) so that one sub-batch's host
+    transcripts overlap another's device stages.  --per-proof restores the r01 path (one glp_prove per proof) for comparison."""
     import threading
+    import numpy as np
     mine = list(gdist.proofs_for_rank(a.batch, grp.rank, grp.world))
+    rng = np.random.default_rng(1000 + grp.rank)
+    descs = [synth.zkdsa_circuit(3, seed=5, private_key=synth.gl.rand(rng, 4), message=synth.gl.rand(rng, 4)) for _ in mine]
     nthr = max(1, min(a.threads, len(mine) or 1))
     workers = []
     for t in range(nthr):
         ctx = glp.Context(local_rank)
-        descs = [synth.zkdsa_circuit(3, seed=1000 + i) for i in mine[t::nthr]]
-        circuit = glp.Circuit(ctx, descs[0]) if descs else None     # one circuit, many witnesses
-        workers.append((ctx, circuit, descs))
+        sub = descs[t::nthr]
+        circuit = glp.Circuit(ctx, descs[0]) if sub else None     # one circuit, many witnesses
+        wires = np.stack([d.wires for d in sub]) if sub else None
+        pis = np.stack([d.public_inputs for d in sub]) if sub else None
+        workers.append([ctx, circuit, sub, wires, pis, None])
 
     def step():
         def run(w):
-            ctx, circuit, descs = w
-            for d in descs:
-                circuit.prove(wires=d.wires, public_inputs=d.public_inputs)
+            ctx, circuit, sub, wires, pis, _ = w
+            if not sub:
+                return
+            if a.per_proof:
+                w[5] = np.stack([circuit.prove(wires=d.wires, public_inputs=d.public_inputs) for d in sub])
+            else:
+                out = []
+                for i0 in range(0, len(sub), a.sub_batch):
+                    out.append(circuit.prove_batch(wires[i0:i0 + a.sub_batch], pis[i0:i0 + a.sub_batch]))
+                w[5] = np.concatenate(out)
         th = [threading.Thread(target=run, args=(w,)) for w in workers]
         for t in th:
             t.start()
@@ -214,26 +230,32 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             t.join()
 
     def device_sync():
-        for ctx, _, _ in workers:
-            ctx.synchronize()
+        for w in workers:
+            w[0].synchronize()
         torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     dt = gdist.timed_steps(grp, step, a.steps, 0, device_sync)
+    # every proof of the last step is checked by the library's verifier (host code), outside the timed region
+    ok = all(bool(w[1].verify(p)) for w in workers if w[5] is not None for p in w[5])
+    ok_all = grp.max_over_ranks(0.0 if ok else 1.0) == 0.0
     if grp.rank == 0:
         print(json.dumps({
             "metric": "proofs/sec for a batch of independent zkdsa simple-signature proofs (BASELINE config 5)",
             "value": a.batch * a.steps / dt, "unit": "proofs/sec", "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic",
-            "config": {"workload": "%d zkdsa proofs (2^3 rows, 4 PoseidonGate rows, 12 public inputs), %d host threads per GPU, "
-                                   "witness from host memory" % (a.batch, nthr),
+            "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all,
+            "config": {"workload": "%d zkdsa proofs (2^3 rows, 4 PoseidonGate rows, 12 public inputs, 16 proof-of-work bits each), %s, %d in "
+                                   "flight per GPU, witnesses from host memory" %
+                                   (a.batch, "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
                        "parallelism": "independent proofs sharded over ranks, no collective"}}))
-    for ctx, circuit, _ in workers:
-        if circuit is not None:
-            circuit.free()
-        ctx.close()
+    for w in workers:
+        if w[1] is not None:
+            w[1].free()
+        w[0].close()
     grp.close()
+    if not ok_all:
+        raise SystemExit("bench.py: glp_verify REJECTED a proof of the batch")
 
 
 def main():

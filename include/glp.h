@@ -219,6 +219,18 @@ GLP_API int glp_prove(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *
 GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *dev_wires,
                              const uint64_t *public_inputs, uint64_t *proof_out);
 
+/* Many independent proofs of ONE circuit in lock step (BASELINE config 5: a batch of zkdsa simple-signature proofs, the unit
+ * [REF src/zkdsa/circuits/mod.rs:24-43,322-339] proves one at a time).  Small circuits are bound by launch and host round-trip
+ * latency when proved one by one; here every device stage is one launch over all num_proofs proofs and every host round trip
+ * carries all their caps / openings, while the num_proofs Fiat-Shamir transcripts run on host threads (GLP_HOST_THREADS, default:
+ * the machine's cores up to 32).  proofs_out[k] is word for word what glp_prove returns for witness k.
+ *   wires          [num_proofs][num_wires][n], host memory, or (wires_on_device != 0) an HBM pointer on the ctx's GPU
+ *   public_inputs  [num_proofs][num_public_inputs]
+ *   proofs_out     [num_proofs][glp_proof_words(circuit)]
+ * Scope: num_challenges = 2 (every CircuitConfig the reference uses). */
+GLP_API int glp_prove_batch(glp_ctx *ctx, const glp_circuit *circuit, uint32_t num_proofs, const uint64_t *wires, int wires_on_device,
+                            const uint64_t *public_inputs, uint64_t *proofs_out);
+
 /* ---- witness generation, the row-local half ------------------------------------------
  * plonky2 `iop/generator.rs::generate_partial_witness` interleaves two kinds of work: the copy-constraint dataflow
  * between rows (stays with the reference's CPU gadget code) and the row-local `SimpleGenerator`s that derive the rest

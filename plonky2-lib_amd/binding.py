@@ -126,6 +126,7 @@ def load_library():
         "glp_session_end": [vp],
         "glp_verify": [vp, vp],
         "glp_verify_n": [vp, vp, sz],
+        "glp_prove_batch": [vp, vp, u32, vp, C.c_int, vp, vp],
         "glp_witness_fill": [vp, vp, vp, C.c_int],
         "glp_witness_columns": [vp, u32, vp],
         "glp_dev_alloc": [vp, sz, C.POINTER(vp)],
@@ -545,6 +546,27 @@ class Circuit:
         words = np.zeros(self.proof_words, np.uint64)
         _chk(load_library().glp_proof_from_bytes(self._h, buf.ctypes.data_as(C.c_void_p), buf.size, _p(words)))
         return words
+
+    def prove_batch(self, wires, public_inputs=None):
+        """glp_prove_batch: wires [K][num_wires][n] (host array) -> proofs [K][proof_words]."""
+        w = _a(wires)
+        if w.ndim != 3 or w[0].size != self._wire_elems:
+            raise GlpError(-1, "wires must be [K][num_wires][2^degree_bits]")
+        K = w.shape[0]
+        pi = _a(np.zeros((K, 0), np.uint64) if public_inputs is None else public_inputs).reshape(K, -1)
+        if pi.shape[1] != self._num_pis:
+            raise GlpError(-1, "%d public inputs per proof, the circuit has %d" % (pi.shape[1], self._num_pis))
+        out = np.zeros((K, self.proof_words), np.uint64)
+        _chk(load_library().glp_prove_batch(self.ctx._h, self._h, K, _p(w), 0, _p(pi) if pi.size else None, _p(out)))
+        return out
+
+    def prove_batch_device(self, dev_wires_ptr, K, public_inputs=None):
+        pi = _a(np.zeros((K, 0), np.uint64) if public_inputs is None else public_inputs).reshape(K, -1)
+        if pi.shape[1] != self._num_pis:
+            raise GlpError(-1, "%d public inputs per proof, the circuit has %d" % (pi.shape[1], self._num_pis))
+        out = np.zeros((K, self.proof_words), np.uint64)
+        _chk(load_library().glp_prove_batch(self.ctx._h, self._h, K, C.c_void_p(dev_wires_ptr), 1, _p(pi) if pi.size else None, _p(out)))
+        return out
 
     def witness_fill(self, dev_wires_ptr, only_advice=False):
         """Row-local witness generation in place on an HBM-resident witness (include/glp.h, glp_witness_fill)."""

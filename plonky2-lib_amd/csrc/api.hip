@@ -327,10 +327,31 @@ void batch_destroy(glp_batch *b) {
 // host_src != nullptr (BATCH_VALUES only): the values are still in host memory; they are copied into dev_in in column
 // chunks on the copy stream while the transforms of the chunks already on the device run on the compute stream.
 int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg, int rate_bits, int cap_height,
-                glp_batch **out, const u64 *host_src) {
+                glp_batch **out, const u64 *host_src, u32 K) {
     GLP_REQUIRE(out, "out is null");
     *out = nullptr;
     GLP_REQUIRE(ncols > 0, "ncols must be positive");
+    GLP_REQUIRE(K >= 1 && (K == 1 || host_src == nullptr), "bad batch arguments");
+    if (K > 1) {
+        // K oracles of one shape: the transforms see K * ncols independent columns, the trees get a proof index
+        GLP_REQUIRE(rate_bits >= 0 && rate_bits <= 4 && cap_height >= 0 && cap_height <= lg + rate_bits && lg <= NTT_MAX_LG, "bad batch shape");
+        const size_t n = (size_t)1 << lg, N = n << rate_bits;
+        std::unique_ptr<glp_batch, void (*)(glp_batch *)> b(new glp_batch(), batch_destroy);
+        b->ctx = c; b->ncols = ncols; b->lg = lg; b->rate_bits = rate_bits; b->cap_height = cap_height; b->K = K;
+        b->ndigests = merkle_num_digests(N, cap_height);
+        const size_t tot = (size_t)K * ncols;
+        GLP_REQUIRE(tot <= 0x7FFFFFFFu, "batch too wide");
+        GLP_TRY(c->alloc((void **)&b->coeffs, tot * n * 8));
+        GLP_TRY(c->alloc((void **)&b->lde, tot * N * 8));
+        GLP_TRY(c->alloc((void **)&b->digests, (size_t)K * b->ndigests * 32));
+        if (input_kind == BATCH_VALUES) GLP_TRY(intt_values_to_coeffs(c, dev_in, b->coeffs, (u32)tot, lg));
+        else if (input_kind == BATCH_COEFFS_NATURAL) GLP_TRY(bitrev_copy(c, dev_in, b->coeffs, (u32)tot, lg));
+        else GLP_HIP(hipMemcpyAsync(b->coeffs, dev_in, tot * n * 8, hipMemcpyDeviceToDevice, c->stream));
+        GLP_TRY(lde_coeffs(c, b->coeffs, b->lde, (u32)tot, lg, rate_bits, glf::GEN));
+        GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests, K, (size_t)ncols * N, b->ndigests * 4));
+        *out = b.release();
+        return GLP_OK;
+    }
     if (lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d > %d (three-pass NTT not built yet)", lg, NTT_MAX_LG);
     GLP_REQUIRE(rate_bits >= 0 && rate_bits <= 4, "rate_bits=%d outside 0..4", rate_bits);
     GLP_REQUIRE(cap_height >= 0 && cap_height <= lg + rate_bits, "cap_height=%d should be at most log2(leaves)=%d", cap_height,

@@ -36,8 +36,11 @@ __device__ __forceinline__ void store_digest(u64 *dst, const u64 s[12]) {
 }
 
 // hash_or_noop of one LDE row per lane.  grid.x * 256 >= N
+// blockIdx.y = proof of a many-proofs batch (glp_prove_batch): LDE matrix and digest array of proof k start
+// k * lde_stride / k * dig_stride words further on; a single proof launches with gridDim.y = 1.
 __global__ __launch_bounds__(256, 4) void k_leaf_hash_lde(const u64 *__restrict__ lde, u64 *__restrict__ digests,
-                                                       u32 ncols, int lg, int rate_bits) {
+                                                       u32 ncols, int lg, int rate_bits, size_t lde_stride, size_t dig_stride) {
+    lde += (size_t)blockIdx.y * lde_stride; digests += (size_t)blockIdx.y * dig_stride;
     const size_t N = (size_t)1 << (lg + rate_bits);
     const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (pos >= N) return;
@@ -74,7 +77,8 @@ __global__ __launch_bounds__(256, 4) void k_leaf_hash_lde(const u64 *__restrict_
 // sponge state spread over 12 lanes (pos::permute_coop).  17 sequential permutations per leaf take ~0.2 ms here
 // instead of ~0.95 ms with one state per lane.
 __global__ __launch_bounds__(256) void k_leaf_hash_lde_coop(const u64 *__restrict__ lde, u64 *__restrict__ digests,
-                                                            u32 ncols, int lg, int rate_bits) {
+                                                            u32 ncols, int lg, int rate_bits, size_t lde_stride, size_t dig_stride) {
+    lde += (size_t)blockIdx.y * lde_stride; digests += (size_t)blockIdx.y * dig_stride;
     const size_t N = (size_t)1 << (lg + rate_bits);
     const int tid = threadIdx.x, l = tid & 15, lane = tid & 63, group_base = lane & ~15;
     const size_t pos = (size_t)blockIdx.x * 16 + (tid >> 4);
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256, 4) void k_leaf_hash_rows(const u64 *__restrict
 }
 
 // one tree level: out[i] = two_to_one(in[2i], in[2i+1])
-__global__ __launch_bounds__(256) void k_merkle_level(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m) {
+__global__ __launch_bounds__(256) void k_merkle_level(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m, size_t dig_stride) {
+    in += (size_t)blockIdx.y * dig_stride; out += (size_t)blockIdx.y * dig_stride;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
     const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(in + 8 * i);
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(256) void k_merkle_level(const u64 *__restrict__ in
 }
 
 // Small levels: one parent hash per 16-lane group (12 lanes active), 16 hashes per 256-thread workgroup.
-__global__ __launch_bounds__(256) void k_merkle_level_coop(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m) {
+__global__ __launch_bounds__(256) void k_merkle_level_coop(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m, size_t dig_stride) {
+    in += (size_t)blockIdx.y * dig_stride; out += (size_t)blockIdx.y * dig_stride;
     const int tid = threadIdx.x, l = tid & 15, lane = tid & 63, group_base = lane & ~15;
     const size_t i = (size_t)blockIdx.x * 16 + (tid >> 4);
     const bool live = i < m;
@@ -154,40 +160,45 @@ __global__ void k_permute_states(u64 *states, size_t count) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
 }
 
-static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height) {
+static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height, u32 K = 1, size_t dig_stride = 0) {
     size_t w = nleaves, cap = (size_t)1 << cap_height;
     u64 *lvl = dev_digests;
     while (w > cap) {
         u64 *nxt = lvl + 4 * w;
         size_t m = w >> 1;
-        if (m <= MERKLE_COOP_MAX_PARENTS)   // few hashes: 12 lanes per hash for latency
-            hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, c->stream, lvl, nxt, m);
+        if (m * K <= MERKLE_COOP_MAX_PARENTS)   // few hashes: 12 lanes per hash for latency
+            hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((m + 15) / 16), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
         else
-            hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, lvl, nxt, m);
+            hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
         GLP_HIP(hipGetLastError());
         lvl = nxt; w = m;
     }
     return GLP_OK;
 }
 
-int merkle_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height) { return build_levels(c, dev_digests, nleaves, cap_height); }
+int merkle_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height, u32 K, size_t dig_stride) {
+    return build_levels(c, dev_digests, nleaves, cap_height, K, dig_stride);
+}
 
-int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, int cap_height, u64 *dev_digests) {
+// K > 1: K trees over K LDE matrices (stride lde_stride words) into K digest arrays (stride dig_stride words)
+int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, int cap_height, u64 *dev_digests, u32 K,
+                    size_t lde_stride, size_t dig_stride) {
     const size_t N = (size_t)1 << (lg + rate_bits);
     if (cap_height < 0 || ((size_t)1 << cap_height) > N)
         return set_error(GLP_ERR_ARG, "cap_height=%d should be at most log2(leaves)=%d", cap_height, lg + rate_bits);
+    GLP_REQUIRE(K >= 1 && K <= 65535, "batch of %u trees outside 1..65535", K);
     {
-        StageScope st(c, "merkle_leaves", (double)N * (8.0 * ncols + 32.0));
-        if (N <= MERKLE_COOP_MAX_LEAVES)
-            hipLaunchKernelGGL(k_leaf_hash_lde_coop, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, c->stream, dev_lde, dev_digests,
-                               ncols, lg, rate_bits);
+        StageScope st(c, "merkle_leaves", (double)N * K * (8.0 * ncols + 32.0));
+        if (N * K <= MERKLE_COOP_MAX_LEAVES)
+            hipLaunchKernelGGL(k_leaf_hash_lde_coop, dim3((unsigned)((N + 15) / 16), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
+                               ncols, lg, rate_bits, lde_stride, dig_stride);
         else
-            hipLaunchKernelGGL(k_leaf_hash_lde, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, c->stream, dev_lde, dev_digests,
-                               ncols, lg, rate_bits);
+            hipLaunchKernelGGL(k_leaf_hash_lde, dim3((unsigned)((N + 255) / 256), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
+                               ncols, lg, rate_bits, lde_stride, dig_stride);
         GLP_HIP(hipGetLastError());
     }
-    StageScope st(c, "merkle_levels", (double)N * 32.0 * 1.5);
-    return build_levels(c, dev_digests, N, cap_height);
+    StageScope st(c, "merkle_levels", (double)N * K * 32.0 * 1.5);
+    return build_levels(c, dev_digests, N, cap_height, K, dig_stride);
 }
 
 int merkle_from_rows(glp_ctx *c, const u64 *dev_rows, size_t nleaves, u32 leaf_len, int cap_height, u64 *dev_digests) {
@@ -200,8 +211,11 @@ int merkle_from_rows(glp_ctx *c, const u64 *dev_rows, size_t nleaves, u32 leaf_l
 }
 
 // out[k * out_stride + col]: a record stride lets the prover gather straight into the proof's query layout
+// blockIdx.y = proof of a batch: lde / leaf_idx / out advance by lde_bstride / count / out_bstride per proof
 __global__ void k_gather_lde_rows(const u64 *__restrict__ lde, u32 ncols, int lg, int rate_bits,
-                                  const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out, size_t out_stride) {
+                                  const u64 *__restrict__ leaf_idx, u32 count, u64 *__restrict__ out, size_t out_stride,
+                                  size_t lde_bstride, size_t out_bstride) {
+    lde += (size_t)blockIdx.y * lde_bstride; leaf_idx += (size_t)blockIdx.y * count; out += (size_t)blockIdx.y * out_bstride;
     const size_t N = (size_t)1 << (lg + rate_bits);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)count * ncols) return;
@@ -215,7 +229,9 @@ __global__ void k_gather_lde_rows(const u64 *__restrict__ lde, u32 ncols, int lg
 
 // leaf index = leaf_idx[k] >> idx_shift (FRI layer r looks at x_index >> sum of the arities so far)
 __global__ void k_gather_paths(const u64 *__restrict__ digests, size_t nleaves, int depth,
-                               const u64 *__restrict__ leaf_idx, u32 idx_shift, u32 count, u64 *__restrict__ out, size_t out_stride) {
+                               const u64 *__restrict__ leaf_idx, u32 idx_shift, u32 count, u64 *__restrict__ out, size_t out_stride,
+                               size_t dig_bstride, size_t out_bstride) {
+    digests += (size_t)blockIdx.y * dig_bstride; leaf_idx += (size_t)blockIdx.y * count; out += (size_t)blockIdx.y * out_bstride;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)count * depth * 4) return;
     const u32 e = (u32)(t & 3);
@@ -227,25 +243,25 @@ __global__ void k_gather_paths(const u64 *__restrict__ digests, size_t nleaves, 
 }
 
 int merkle_gather_lde_rows(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, const u64 *dev_leaf_idx,
-                           u32 count, u64 *dev_out, size_t out_stride) {
+                           u32 count, u64 *dev_out, size_t out_stride, u32 K, size_t lde_bstride, size_t out_bstride) {
     if (out_stride == 0) out_stride = ncols;
     const size_t total = (size_t)count * ncols;
     if (!total) return GLP_OK;
-    hipLaunchKernelGGL(k_gather_lde_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dev_lde, ncols, lg,
-                       rate_bits, dev_leaf_idx, count, dev_out, out_stride);
+    hipLaunchKernelGGL(k_gather_lde_rows, dim3((unsigned)((total + 255) / 256), K), dim3(256), 0, c->stream, dev_lde, ncols, lg,
+                       rate_bits, dev_leaf_idx, count, dev_out, out_stride, lde_bstride, out_bstride);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }
 
 int merkle_gather_paths(glp_ctx *c, const u64 *dev_digests, size_t nleaves, int cap_height, const u64 *dev_leaf_idx,
-                        u32 count, u64 *dev_out, size_t out_stride, u32 idx_shift) {
+                        u32 count, u64 *dev_out, size_t out_stride, u32 idx_shift, u32 K, size_t dig_bstride, size_t out_bstride) {
     int depth = 0;
     for (size_t w = nleaves; w > ((size_t)1 << cap_height); w >>= 1) depth++;
     if (out_stride == 0) out_stride = (size_t)depth * 4;
     const size_t total = (size_t)count * depth * 4;
     if (!total) return GLP_OK;
-    hipLaunchKernelGGL(k_gather_paths, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, dev_digests, nleaves,
-                       depth, dev_leaf_idx, idx_shift, count, dev_out, out_stride);
+    hipLaunchKernelGGL(k_gather_paths, dim3((unsigned)((total + 255) / 256), K), dim3(256), 0, c->stream, dev_digests, nleaves,
+                       depth, dev_leaf_idx, idx_shift, count, dev_out, out_stride, dig_bstride, out_bstride);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }

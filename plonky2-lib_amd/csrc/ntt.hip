@@ -4,6 +4,7 @@
 // `polynomial/mod.rs` (lde, coset_fft_with_options) as called from
 // `PolynomialBatch::from_values / from_coeffs` on the prove() path
 // [REF src/ecdsa/gadgets/ecdsa.rs:349].  No MFMA: 64-bit modular integer butterflies.
+#include <algorithm>
 #include "ntt.h"
 
 namespace glp {
@@ -788,7 +789,19 @@ static void launch_strided16e(glp_ctx *c, const u64 *in, u64 *out, const u64 *tw
 // ------------------------------------------------------------------------------------------
 static size_t contig_lds_bytes(int lgB) { return (((size_t)1 << lgB) + ((size_t)1 << lgB) / 2 + 1 + 64 + 64 + 16) * sizeof(u64); }
 
+static int lde_coeffs_chunk(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift);
+// grid.y carries (column, coset plane, outer block): at most 65535.  Wide inputs (the K-proof batches of glp_prove_batch:
+// K * num_wires columns) go through in column chunks.
 int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift) {
+    if (lg < 0 || lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d outside the supported range 0..%d", lg, NTT_MAX_LG);
+    if (rate_bits < 0 || rate_bits > 4) return set_error(GLP_ERR_UNSUPPORTED, "rate_bits=%d outside 0..4", rate_bits);
+    const u32 per = 65535u >> (rate_bits + (lg > NTT_2PASS_LG ? lg - NTT_2PASS_LG : 0));
+    const size_t n = (size_t)1 << lg;
+    for (u32 c0 = 0; c0 < ncols; c0 += per)
+        GLP_TRY(lde_coeffs_chunk(c, dev_coeffs + (size_t)c0 * n, dev_lde + ((size_t)c0 * n << rate_bits), std::min(per, ncols - c0), lg, rate_bits, shift));
+    return GLP_OK;
+}
+static int lde_coeffs_chunk(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift) {
     if (ncols == 0) return GLP_OK;
     LdePlan *lp;
     GLP_TRY(get_lde_plan(c, lg, rate_bits, shift, &lp));
@@ -840,7 +853,16 @@ int ntt_coeffs_to_values(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_values, u32
     return lde_coeffs(c, dev_coeffs, dev_values, ncols, lg, 0, 1);
 }
 
+static int intt_chunk(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg);
 int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg) {
+    if (lg < 0 || lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d outside the supported range 0..%d", lg, NTT_MAX_LG);
+    const u32 per = 65535u >> (lg > NTT_2PASS_LG ? lg - NTT_2PASS_LG : 0);
+    const size_t n = (size_t)1 << lg;
+    for (u32 c0 = 0; c0 < ncols; c0 += per)
+        GLP_TRY(intt_chunk(c, dev_values + (size_t)c0 * n, dev_coeffs + (size_t)c0 * n, std::min(per, ncols - c0), lg));
+    return GLP_OK;
+}
+static int intt_chunk(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg) {
     if (ncols == 0) return GLP_OK;
     NttPlan *np;
     GLP_TRY(get_ntt_plan(c, lg, &np));

@@ -66,6 +66,9 @@ struct PPArgs {
     u64 betas[MAXCH], gammas[MAXCH];
     u64 w_n;
     u32 lg, nr, nch, npp, qdf;
+    // many-proofs batch (blockIdx.y = proof): challenges from chal[proof][2 MAXCH] (betas, gammas), arrays strided per proof
+    const u64 *chal;
+    size_t wires_stride, zp_stride;
 };
 // K5a: per row, the running products of the quotient chunks  prod_{j in chunk} (w_j + beta k_j x + gamma)/(w_j + beta sigma_j + gamma)
 template <int NCH>
@@ -73,6 +76,13 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
     const size_t n = (size_t)1 << a.lg;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    u64 betas[MAXCH], gammas[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) { betas[c] = a.betas[c]; gammas[c] = a.gammas[c]; }
+    if (a.chal) {
+        const size_t pk = blockIdx.y;
+        a.wires += pk * a.wires_stride; a.zp += pk * a.zp_stride; a.dens += pk * a.zp_stride;
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) { betas[c] = a.chal[pk * 2 * MAXCH + c]; gammas[c] = a.chal[pk * 2 * MAXCH + MAXCH + c]; }
+    }
     const u64 x = dpow(a.w_n, i);
     // Pass 1: prefix products of the chunk numerators (into the output columns) and the chunk denominators
     // (into `dens`); pass 2 walks back down with ONE field inversion per challenge instead of one per chunk:
@@ -87,8 +97,8 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
             const u64 w = a.wires[(size_t)j * n + i], s = a.sigmas[(size_t)j * n + i];
             const u64 kx = mul(a.k_is[j], x);
             _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-                num[c] = mul(num[c], add(add(w, mul(a.betas[c], kx)), a.gammas[c]));
-                den[c] = mul(den[c], add(add(w, mul(a.betas[c], s)), a.gammas[c]));
+                num[c] = mul(num[c], add(add(w, mul(betas[c], kx)), gammas[c]));
+                den[c] = mul(den[c], add(add(w, mul(betas[c], s)), gammas[c]));
             }
         }
         _Pragma("unroll") for (int c = 0; c < NCH; c++) {
@@ -111,8 +121,9 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
     }
 }
 // K5b: product of each block of 256 row products
-__global__ __launch_bounds__(256) void k_pp_block_tot(const u64 *zp, u64 *tot, u32 lg, u32 nblocks) {
+__global__ __launch_bounds__(256) void k_pp_block_tot(const u64 *zp, u64 *tot, u32 lg, u32 nblocks, size_t zp_stride) {
     __shared__ u64 sh[256];
+    zp += (size_t)blockIdx.z * zp_stride; tot += (size_t)blockIdx.z * gridDim.y * nblocks;
     const size_t n = (size_t)1 << lg;
     const u32 c = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     const size_t i = (size_t)b * 256 + t;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pp_block_tot(const u64 *zp, u64 *tot, u
 __global__ __launch_bounds__(256) void k_pp_scan_tot(u64 *tot, u32 nblocks) {
     __shared__ u64 sh[256];
     const u32 c = blockIdx.x, t = threadIdx.x;
-    u64 *v = tot + (size_t)c * nblocks;
+    u64 *v = tot + ((size_t)blockIdx.y * gridDim.x + c) * nblocks;
     const u32 m = (nblocks + 255) / 256;
     u64 loc = 1;
     for (u32 k = t * m; k < min((t + 1) * m, nblocks); k++) loc = mul(loc, v[k]);
@@ -137,8 +148,9 @@ __global__ __launch_bounds__(256) void k_pp_scan_tot(u64 *tot, u32 nblocks) {
     for (u32 k = t * m; k < min((t + 1) * m, nblocks); k++) { u64 x = v[k]; v[k] = acc; acc = mul(acc, x); }
 }
 // K5d: Z(x_i) = prefix(block) * in-block exclusive scan; partial products *= Z
-__global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 lg, u32 nblocks, u32 nch, u32 npp) {
+__global__ __launch_bounds__(256) void k_pp_apply(u64 *zp, const u64 *tot, u32 lg, u32 nblocks, u32 nch, u32 npp, size_t zp_stride) {
     __shared__ u64 sh[2][256];
+    zp += (size_t)blockIdx.z * zp_stride; tot += (size_t)blockIdx.z * gridDim.y * nblocks;
     const size_t n = (size_t)1 << lg;
     const u32 c = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
     const size_t i = (size_t)b * 256 + t;
@@ -244,18 +256,36 @@ __device__ __forceinline__ u64 acc2_reduce(const AccLimb &a) {    // canonical
     return acc_reduce(w);
 }
 
-struct QArgs {
-    const u64 *cs, *wl, *zl;        // coset-major LDEs [ncols][R][n]
-    u64 *out;                       // [nch][Rq][n]
+struct QArgs {                      // per circuit and FRI domain: the same for every proof of a batch
+    const u64 *cs;                  // coset-major LDE [ncols][R][n] of constants ++ sigmas
     const DevGate *gates;
-    const u64 *k_is, *apow;         // apow [nch][nterms]
-    u64 betas[MAXCH], gammas[MAXCH], pih[4];
+    const u64 *k_is;
     u64 shift_r[MAXR], zh[MAXR], zh_inv[MAXR];   // per evaluated plane
     u64 w_n, n_field;
     u32 lg, rb, step, nc, nsel, nr, nw, nch, npp, qdf, num_gates, nterms, many_selectors, gate_mode;
     u32 k_ratio;                    // != 0: k_is[j] = k_ratio^j (plonky2's get_unique_coset_shifts: powers of the generator 7)
     const u64 *l0;                  // [Rq][n]: L_0(x) = Z_H(x) / (n (x - 1)) on the evaluated planes (k_l0_table)
 };
+struct QProof {                     // per proof
+    const u64 *wl, *zl;             // coset-major LDEs of the wires and of Z ++ partial products
+    u64 *out;                       // [nch][Rq][n]
+    const u64 *apow;                // [nch][nterms] powers of the alphas
+    u64 betas[MAXCH], gammas[MAXCH], pih[4];
+};
+// many-proofs batch (glp_prove_batch): blockIdx.z = proof; arrays advance by a stride per proof, challenges and the public-input
+// hash come from pp[proof][3 MAXCH] (betas, gammas, pih).  pp == nullptr: a single proof described by the QProof kernel argument.
+struct QBatch { const u64 *pp; size_t wl_stride, zl_stride, out_stride, apow_stride; };
+static_assert(MAXCH == 4, "pp layout: 4 betas, 4 gammas, 4 words of the public-input hash");
+__device__ __forceinline__ QProof q_proof(const QProof &p0, const QBatch &b) {
+    QProof p = p0;
+    if (b.pp) {
+        const size_t k = blockIdx.z;
+        p.wl += k * b.wl_stride; p.zl += k * b.zl_stride; p.out += k * b.out_stride; p.apow += k * b.apow_stride;
+        const u64 *q = b.pp + k * 3 * MAXCH;
+        _Pragma("unroll") for (int c = 0; c < MAXCH; c++) { p.betas[c] = q[c]; p.gammas[c] = q[MAXCH + c]; p.pih[c] = q[2 * MAXCH + c]; }
+    }
+    return p;
+}
 // L_0 on the evaluated planes.  One thread owns position q of every plane and inverts the Rq denominators n (x_rq - 1)
 // with ONE field inversion (Montgomery's trick) instead of one per point inside k_quotient.
 __global__ __launch_bounds__(256) void k_l0_table(QArgs a, u64 *out, u32 Rq) {
@@ -289,12 +319,12 @@ __device__ __forceinline__ u64 gate_filter(const QArgs &a, const DevGate &g, siz
 // HEAD_ONLY (the four base-4 limb gates of plonky2_u32): skip the limb columns -- their range products, base-4 sums and the
 // sum-equals-wire constraints -- which k_quotient_limbs evaluates for all fused gates from ONE read of the wire planes.
 template <int NCH, int TYPE, bool HEAD_ONLY = false>
-__device__ __forceinline__ void gate_terms(const QArgs &a, const DevGate &g, size_t N, size_t slot, u32 k0, AccLimb (&ga)[MAXCH]) {
+__device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, const DevGate &g, size_t N, size_t slot, u32 k0, AccLimb (&ga)[MAXCH]) {
     const u32 nt = a.nterms;
-    const u64 *W = a.wl + slot;                       // wire j  -> W[j * N]
+    const u64 *W = p.wl + slot;                       // wire j  -> W[j * N]
     const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
     {
-        const u64 *ap = a.apow + k0;
+        const u64 *ap = p.apow + k0;
 #define EMIT(k, v)                                                                     \
     do {                                                                               \
         const u64 _v = (v);                                                            \
@@ -324,7 +354,7 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const DevGate &g, siz
             for (u32 i = 0; i < g.p0; i++) EMIT(i, sub(GC[(size_t)i * N], W[(size_t)i * N]));
             break;
         case GLP_GATE_PUBLIC_INPUT:
-            for (u32 i = 0; i < 4; i++) EMIT(i, sub(W[(size_t)i * N], a.pih[i]));
+            for (u32 i = 0; i < 4; i++) EMIT(i, sub(W[(size_t)i * N], p.pih[i]));
             break;
         case GLP_GATE_ARITHMETIC: {
             const u64 c0 = GC[0], c1 = GC[N];
@@ -578,11 +608,11 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const DevGate &g, siz
 // TYPE >= 0 compiles a single gate body (per-gate kernels: small register footprint, high occupancy); TYPE = -1
 // keeps the run-time switch (monolithic fallback).
 template <int NCH, int TYPE>
-__device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
+__device__ __forceinline__ void gate_contrib(const QArgs &a, const QProof &p, const DevGate &g, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
     const u64 filter = gate_filter(a, g, N, slot);
     AccLimb ga[MAXCH];
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[c]);
-    gate_terms<NCH, TYPE, false>(a, g, N, slot, k0, ga);
+    gate_terms<NCH, TYPE, false>(a, p, g, N, slot, k0, ga);
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[c])));
 }
 
@@ -590,15 +620,15 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const DevGate &g, s
 struct LightArgs { u32 count; u32 gi[8]; };
 // The HBM-bound gate types (Constant, PublicInput, Arithmetic, BaseSum, RandomAccess), evaluated one after the other
 template <int NCH>
-__device__ __forceinline__ void light_gates(const QArgs &a, const LightArgs &la, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
+__device__ __forceinline__ void light_gates(const QArgs &a, const QProof &p, const LightArgs &la, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
     for (u32 t = 0; t < la.count; t++) {
         const DevGate g = a.gates[la.gi[t]];
         switch (g.type) {                      // uniform: every lane runs the same gate
-        case GLP_GATE_CONSTANT: gate_contrib<NCH, GLP_GATE_CONSTANT>(a, g, N, slot, k0, acc); break;
-        case GLP_GATE_PUBLIC_INPUT: gate_contrib<NCH, GLP_GATE_PUBLIC_INPUT>(a, g, N, slot, k0, acc); break;
-        case GLP_GATE_ARITHMETIC: gate_contrib<NCH, GLP_GATE_ARITHMETIC>(a, g, N, slot, k0, acc); break;
-        case GLP_GATE_BASE_SUM: gate_contrib<NCH, GLP_GATE_BASE_SUM>(a, g, N, slot, k0, acc); break;
-        case GLP_GATE_RANDOM_ACCESS: gate_contrib<NCH, GLP_GATE_RANDOM_ACCESS>(a, g, N, slot, k0, acc); break;
+        case GLP_GATE_CONSTANT: gate_contrib<NCH, GLP_GATE_CONSTANT>(a, p, g, N, slot, k0, acc); break;
+        case GLP_GATE_PUBLIC_INPUT: gate_contrib<NCH, GLP_GATE_PUBLIC_INPUT>(a, p, g, N, slot, k0, acc); break;
+        case GLP_GATE_ARITHMETIC: gate_contrib<NCH, GLP_GATE_ARITHMETIC>(a, p, g, N, slot, k0, acc); break;
+        case GLP_GATE_BASE_SUM: gate_contrib<NCH, GLP_GATE_BASE_SUM>(a, p, g, N, slot, k0, acc); break;
+        case GLP_GATE_RANDOM_ACCESS: gate_contrib<NCH, GLP_GATE_RANDOM_ACCESS>(a, p, g, N, slot, k0, acc); break;
         default: break;
         }
     }
@@ -609,7 +639,8 @@ __device__ __forceinline__ void light_gates(const QArgs &a, const LightArgs &la,
 // permutation terms are VALU-bound and the light gates HBM-bound, so in one launch the waves in one phase fill the other
 // phase's idle unit (separately: 3.3 + 2.75 ms at the headline size)
 template <int NCH, int GATES>
-__global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, LightArgs la) {
+__global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, QProof p0, QBatch qb, LightArgs la) {
+    const QProof p = q_proof(p0, qb);
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
@@ -619,14 +650,14 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, L
     constexpr u32 nch = NCH; const u32 nchunks = a.npp + 1, nt = a.nterms;
     u64 acc[MAXCH], zx[MAXCH], zg[MAXCH];
     Acc160 pa[MAXCH];
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) { acc_zero(pa[c]); zx[c] = a.zl[(size_t)c * N + slot]; zg[c] = a.zl[(size_t)c * N + slot_next]; }
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) { acc_zero(pa[c]); zx[c] = p.zl[(size_t)c * N + slot]; zg[c] = p.zl[(size_t)c * N + slot_next]; }
     const u64 l0 = a.l0[(size_t)rq * n + q];
     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
         const u64 t = mul(l0, sub(zx[c], 1));
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + c]);
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, p.apow[c2 * nt + c]);
     }
     u64 bkx[MAXCH];                                    // beta_c k_j x for the next wire j (k_ratio path)
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) bkx[c] = mul_nc(a.betas[c], x);
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) bkx[c] = mul_nc(p.betas[c], x);
     for (u32 chunk = 0; chunk < nchunks; chunk++) {
         u64 num[MAXCH], den[MAXCH];
         _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
@@ -635,7 +666,7 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, L
             u64 w8[8], s8[8];
 #pragma unroll
             for (int t = 0; t < 8; t++)
-                if (jb + t < j1) { w8[t] = a.wl[(size_t)(jb + t) * N + slot]; s8[t] = a.cs[(size_t)(a.nc + jb + t) * N + slot]; }
+                if (jb + t < j1) { w8[t] = p.wl[(size_t)(jb + t) * N + slot]; s8[t] = a.cs[(size_t)(a.nc + jb + t) * N + slot]; }
 #pragma unroll
             for (int t = 0; t < 8; t++)
                 if (jb + t < j1) {
@@ -646,20 +677,20 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, L
                     u64 kx = 0;
                     if (!a.k_ratio) kx = mul_nc(a.k_is[jb + t], x);
                     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-                        const u64 wg = add(w8[t], a.gammas[c]);
-                        const u64 bk = a.k_ratio ? bkx[c] : mul_nc(a.betas[c], kx);
+                        const u64 wg = add(w8[t], p.gammas[c]);
+                        const u64 bk = a.k_ratio ? bkx[c] : mul_nc(p.betas[c], kx);
                         num[c] = mul_nc(num[c], add_cnc(wg, bk));
-                        den[c] = mul_nc(den[c], add_cnc(wg, mul_nc(a.betas[c], s8[t])));
+                        den[c] = mul_nc(den[c], add_cnc(wg, mul_nc(p.betas[c], s8[t])));
                         if (a.k_ratio) bkx[c] = mul_small_nc(bkx[c], a.k_ratio);
                     }
                 }
         }
         _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-            const u64 prev = chunk == 0 ? zx[c] : a.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
-            const u64 next = chunk == nchunks - 1 ? zg[c] : a.zl[(size_t)(nch + c * a.npp + chunk) * N + slot];
+            const u64 prev = chunk == 0 ? zx[c] : p.zl[(size_t)(nch + c * a.npp + chunk - 1) * N + slot];
+            const u64 next = chunk == nchunks - 1 ? zg[c] : p.zl[(size_t)(nch + c * a.npp + chunk) * N + slot];
             const u64 t = sub(mul(prev, num[c]), mul(next, den[c]));
             const u32 k = nch + c * nchunks + chunk;
-            _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, a.apow[c2 * nt + k]);
+            _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc_fma(pa[c2], t, p.apow[c2 * nt + k]);
         }
     }
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
@@ -667,17 +698,18 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, L
     if constexpr (GATES == 1) {                        // monolithic: every gate here
         for (u32 gi = 0; gi < a.num_gates; gi++) {
             const DevGate g = a.gates[gi];
-            gate_contrib<NCH, -1>(a, g, N, slot, k0, acc);
+            gate_contrib<NCH, -1>(a, p, g, N, slot, k0, acc);
         }
     }
-    if constexpr (GATES == 2) light_gates<NCH>(a, la, N, slot, k0, acc);
+    if constexpr (GATES == 2) light_gates<NCH>(a, p, la, N, slot, k0, acc);
     const size_t Rq = (size_t)gridDim.y;
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) a.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) p.out[((size_t)c * Rq + rq) * n + q] = mul(acc[c], a.zh_inv[rq]);
 }
 
 // One gate type per launch (gate_mode = 1): out[c][plane][q] += zh_inv * filter * sum_k constraint_k alpha_c^(k0 + k)
 template <int NCH, int TYPE>
-__global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, u32 gi) {
+__global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, QProof p0, QBatch qb, u32 gi) {
+    const QProof p = q_proof(p0, qb);
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
@@ -686,10 +718,10 @@ __global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, u32 gi) {
     u64 acc[MAXCH];
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
     const DevGate g = a.gates[gi];
-    gate_contrib<NCH, TYPE>(a, g, N, slot, (u32)NCH + (u32)NCH * (a.npp + 1), acc);
+    gate_contrib<NCH, TYPE>(a, p, g, N, slot, (u32)NCH + (u32)NCH * (a.npp + 1), acc);
     const size_t Rq = (size_t)gridDim.y;
     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-        u64 *o = a.out + ((size_t)c * Rq + rq) * n + q;
+        u64 *o = p.out + ((size_t)c * Rq + rq) * n + q;
         *o = add(*o, mul(acc[c], a.zh_inv[rq]));
     }
 }
@@ -712,15 +744,16 @@ __global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, u32 gi) {
 constexpr int LIMB_SLOTS = 4;
 struct LimbArgs { const u64 *desc; u32 count, jlo, jhi; u32 gi[LIMB_SLOTS]; u32 extra_count, extra_gi[4]; };
 template <int NCH>
-__global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, LimbArgs la) {
+__global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, QBatch qb, LimbArgs la) {
+    const QProof p = q_proof(p0, qb);
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     const u32 rq = blockIdx.y, r = rq * a.step;
     const size_t slot = (size_t)r * n + q;
     const u32 k0 = (u32)NCH + (u32)NCH * (a.npp + 1), nt = a.nterms;
-    const u64 *W = a.wl + slot;
-    const u64 *ap = a.apow + k0;
+    const u64 *W = p.wl + slot;
+    const u64 *ap = p.apow + k0;
     AccLimb ga[LIMB_SLOTS][MAXCH];
     Base4Sum bs[LIMB_SLOTS];
     _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
@@ -732,9 +765,9 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, LimbArgs la)
         if ((u32)s < la.count) {
             const DevGate g = a.gates[la.gi[s]];
             switch (g.type) {
-            case GLP_GATE_U32_ARITHMETIC: gate_terms<NCH, GLP_GATE_U32_ARITHMETIC, true>(a, g, N, slot, k0, ga[s]); break;
-            case GLP_GATE_U32_ADD_MANY: gate_terms<NCH, GLP_GATE_U32_ADD_MANY, true>(a, g, N, slot, k0, ga[s]); break;
-            case GLP_GATE_U32_SUBTRACTION: gate_terms<NCH, GLP_GATE_U32_SUBTRACTION, true>(a, g, N, slot, k0, ga[s]); break;
+            case GLP_GATE_U32_ARITHMETIC: gate_terms<NCH, GLP_GATE_U32_ARITHMETIC, true>(a, p, g, N, slot, k0, ga[s]); break;
+            case GLP_GATE_U32_ADD_MANY: gate_terms<NCH, GLP_GATE_U32_ADD_MANY, true>(a, p, g, N, slot, k0, ga[s]); break;
+            case GLP_GATE_U32_SUBTRACTION: gate_terms<NCH, GLP_GATE_U32_SUBTRACTION, true>(a, p, g, N, slot, k0, ga[s]); break;
             default: break;                    // U32RangeCheck: limb work only
             }
         }
@@ -779,11 +812,11 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, LimbArgs la)
     }
     for (u32 t = 0; t < la.extra_count; t++) {             // after the limb accumulators are dead (register budget)
         const DevGate g = a.gates[la.extra_gi[t]];
-        if (g.type == GLP_GATE_COMPARISON) gate_contrib<NCH, GLP_GATE_COMPARISON>(a, g, N, slot, k0, acc);
+        if (g.type == GLP_GATE_COMPARISON) gate_contrib<NCH, GLP_GATE_COMPARISON>(a, p, g, N, slot, k0, acc);
     }
     const size_t Rq = (size_t)gridDim.y;
     _Pragma("unroll") for (int c = 0; c < NCH; c++) {
-        u64 *o = a.out + ((size_t)c * Rq + rq) * n + q;
+        u64 *o = p.out + ((size_t)c * Rq + rq) * n + q;
         *o = add(*o, mul(acc[c], a.zh_inv[rq]));
     }
 }
@@ -812,20 +845,31 @@ __global__ __launch_bounds__(256) void k_quotient_combine(QCArgs a) {
 }
 
 // zt[p] = z^bitrev(p)  (extension), from z^(2^b), b < lg
-struct ZTArgs { u64 *zt; ext2 zp2[24]; u32 lg; };
+// batch (zeta_b != nullptr, blockIdx.y = proof): the point comes from zeta_b[proof][2] and its squarings are made here
+struct ZTArgs { u64 *zt; ext2 zp2[24]; u32 lg; const u64 *zeta_b; size_t zeta_stride; };
 __global__ __launch_bounds__(256) void k_zeta_table(ZTArgs a) {
     const size_t n = (size_t)1 << a.lg;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const u32 k = bitrev32((u32)p, a.lg);
     ext2 acc = e_from(1);
-    for (u32 b = 0; b < a.lg; b++) if ((k >> b) & 1) acc = e_mul(acc, a.zp2[b]);
+    if (a.zeta_b) {
+        const u64 *z = a.zeta_b + (size_t)blockIdx.y * a.zeta_stride;
+        ext2 sq = e_make(z[0], z[1]);
+        for (u32 b = 0; b < a.lg; b++) { if ((k >> b) & 1) acc = e_mul(acc, sq); sq = e_sqr(sq); }
+        a.zt += (size_t)blockIdx.y * 2 * n;
+    } else {
+        for (u32 b = 0; b < a.lg; b++) if ((k >> b) & 1) acc = e_mul(acc, a.zp2[b]);
+    }
     a.zt[2 * p] = acc.a; a.zt[2 * p + 1] = acc.b;
 }
 // K7: partial sums of  sum_p coeffs[col][p] * zt[p]   grid = (OPEN_BLOCKS, ncols)
 constexpr int OPEN_BLOCKS = 32;
-__global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *zt, u64 *partial, u32 lg) {
+// blockIdx.z = proof of a batch: coefficients / table / partial sums advance by the given strides (0 = shared by all proofs)
+__global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *zt, u64 *partial, u32 lg, size_t coeffs_bstride,
+                                                  size_t zt_bstride, size_t partial_bstride) {
     __shared__ u64 sa[256], sb[256];
+    coeffs += (size_t)blockIdx.z * coeffs_bstride; zt += (size_t)blockIdx.z * zt_bstride; partial += (size_t)blockIdx.z * partial_bstride;
     const size_t n = (size_t)1 << lg;
     const u32 col = blockIdx.y, t = threadIdx.x;
     // n / (OPEN_BLOCKS * 256) <= 2^11 terms per thread, flushed every ACC_MAX_TERMS: carry-free limb accumulators
@@ -860,11 +904,22 @@ struct FVArgs {
     ext2 red0, red1, zeta, zeta_next, shift_acc;   // shift_acc = alpha^nch
     u64 w_n, g;
     u32 lg, rb, nch;
+    // many-proofs batch (blockIdx.y = proof): pp[proof][10] = red0, red1, zeta, zeta_next, shift_acc; strides per proof
+    const u64 *pp;
+    size_t lde_stride[4], apow_stride, out_stride;
 };
 __global__ __launch_bounds__(256) void k_final_values(FVArgs a) {
     const size_t n = (size_t)1 << a.lg, N = n << a.rb;
     const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
+    if (a.pp) {
+        const size_t pk = blockIdx.y;
+        const u64 *v = a.pp + pk * 10;
+        a.red0 = e_make(v[0], v[1]); a.red1 = e_make(v[2], v[3]); a.zeta = e_make(v[4], v[5]); a.zeta_next = e_make(v[6], v[7]);
+        a.shift_acc = e_make(v[8], v[9]);
+        _Pragma("unroll") for (int k = 0; k < 4; k++) a.lde[k] += pk * a.lde_stride[k];
+        a.apow += pk * a.apow_stride; a.out += pk * a.out_stride;
+    }
     // sum_j alpha^j f_j(x): the base-field value is cut into 22-bit limbs once and multiplied into carry-free
     // accumulators for the two extension coordinates (flushed every ACC_MAX_TERMS columns)
     ext2 acc0 = e_from(0), acc1 = e_from(0);
@@ -906,7 +961,9 @@ __global__ __launch_bounds__(256) void k_scale_bitrev_pow(u64 *data, u64 base, u
 
 // K9a: FRI commit-phase leaves.  vals = coset-major LDE [2][R][ncur] of the current polynomial (L = R*ncur
 // points); leaf m = the `arity` extension values at natural indices bitrev_L(m*arity + t).  Lane = M' = bitrev(m).
-__global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab) {
+__global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab, size_t vals_bstride,
+                                                       size_t dig_bstride) {
+    vals += (size_t)blockIdx.y * vals_bstride; digests += (size_t)blockIdx.y * dig_bstride;     // blockIdx.y = proof of a batch
     const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
     const size_t Mp = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (Mp >= nleaves) return;
@@ -931,7 +988,9 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash(const u64 *vals, u64 *dig
     reinterpret_cast<ulonglong2 *>(digests + 4 * m)[1] = d1;
 }
 // K9a, latency form for small layers: one leaf per 16-lane group, sponge state on 12 lanes.
-__global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab) {
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab, size_t vals_bstride,
+                                                            size_t dig_bstride) {
+    vals += (size_t)blockIdx.y * vals_bstride; digests += (size_t)blockIdx.y * dig_bstride;
     const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
     const int tid = threadIdx.x, l = tid & 15, lane = tid & 63, group_base = lane & ~15;
     const size_t Mp0 = (size_t)blockIdx.x * 16 + (tid >> 4);
@@ -952,8 +1011,13 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64 *vals, u64
     if (live && l < 4) digests[4 * m + l] = x;
 }
 // K9b: fold coefficients (bit-reversed layout): new[p'] = sum_t beta^t old[bitrev(t) * nnew + p']
-__global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ext2 beta, u32 lg_old, u32 ab) {
+// batch (beta_b != nullptr, blockIdx.y = proof): beta from beta_b[proof][2]; coefficient arrays [proof][2][n]
+__global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ext2 beta, u32 lg_old, u32 ab, const u64 *beta_b) {
     const size_t nold = (size_t)1 << lg_old, nnew = nold >> ab;
+    if (beta_b) {
+        beta = e_make(beta_b[2 * blockIdx.y], beta_b[2 * blockIdx.y + 1]);
+        oldc += (size_t)blockIdx.y * 2 * nold; newc += (size_t)blockIdx.y * 2 * nnew;
+    }
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= nnew) return;
     ext2 acc = e_from(0);
@@ -965,7 +1029,8 @@ __global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ex
 }
 // leaf evals for the query phase: out[k][2*t..] = the arity values of leaf idx[k]
 __global__ void k_fri_gather_leaf(const u64 *vals, u32 lgL, u32 rb, u32 ab, const u64 *idx, u32 idx_shift, u32 count, u64 *out,
-                                  size_t out_stride) {
+                                  size_t out_stride, size_t vals_bstride, size_t out_bstride) {
+    vals += (size_t)blockIdx.y * vals_bstride; idx += (size_t)blockIdx.y * count; out += (size_t)blockIdx.y * out_bstride;
     const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
     const u32 arity = 1u << ab;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -989,6 +1054,30 @@ __global__ __launch_bounds__(256) void k_pow(PowArgs a) {
     s[a.pos] = cand;        // candidates stay far below p
     pos::permute(s);
     if (a.bits == 0 || (s[7] >> (64 - a.bits)) == 0) atomicMin(a.best, (unsigned long long)cand);
+}
+
+// K10 for a batch: blockIdx.y = proof, each with its own sponge state st_b[proof][12] and input position pos_b[proof].  The
+// workgroups of one proof sweep the candidates in increasing order, gridDim.x * 256 at a time, and stop as soon as the
+// smallest witness found so far (best[proof]) lies below everything they would still test: the result is the smallest
+// witness regardless of scheduling, and every wave leaves the loop (a witness exists below 2^40 with overwhelming probability;
+// the sweep is cut there in any case).
+__global__ __launch_bounds__(256) void k_pow_batch(const u64 *st_b, const u32 *pos_b, u32 bits, unsigned long long *best) {
+    const u32 pk = blockIdx.y;
+    u64 st[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = st_b[(size_t)pk * 12 + i];
+    const u32 pos = pos_b[pk];
+    volatile unsigned long long *mine = best + pk;
+    for (u64 base = (u64)blockIdx.x * 256; base < (1ull << 40); base += (u64)gridDim.x * 256) {
+        if (*mine <= base) break;                    // something smaller than this whole chunk is already known
+        const u64 cand = base + threadIdx.x;
+        u64 s[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = st[i];
+        for (u32 i = 0; i < 8; i++) if (i == pos) s[i] = cand;      // candidates stay far below p
+        pos::permute(s);
+        if (bits == 0 || (s[7] >> (64 - bits)) == 0) atomicMin(best + pk, (unsigned long long)cand);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -1028,7 +1117,7 @@ int batch_cap_host(glp_ctx *c, const glp_batch *b, std::vector<u64> &cap) {
 // evaluate every polynomial of a batch at z: launch only; partial sums land in dev_partial [ncols][OPEN_BLOCKS][2]
 int open_batch_launch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial) {
     dim3 g(OPEN_BLOCKS, b->ncols);
-    hipLaunchKernelGGL(k_open_dot, g, dim3(256), 0, c->stream, b->coeffs, dev_zt, dev_partial, (u32)b->lg);
+    hipLaunchKernelGGL(k_open_dot, g, dim3(256), 0, c->stream, b->coeffs, dev_zt, dev_partial, (u32)b->lg, (size_t)0, (size_t)0, (size_t)0);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }
@@ -1043,7 +1132,7 @@ void open_batch_finish(const u64 *h, u32 ncols, std::vector<ext2> &out) {
 }
 int zeta_table(glp_ctx *c, ext2 z, int lg, u64 *dev_zt) {
     ZTArgs za;
-    za.zt = dev_zt; za.lg = (u32)lg;
+    za.zt = dev_zt; za.lg = (u32)lg; za.zeta_b = nullptr; za.zeta_stride = 0;
     ext2 p = z;
     for (int b = 0; b < 24; b++) { za.zp2[b] = p; p = e_sqr(p); }
     hipLaunchKernelGGL(k_zeta_table, dim3(nblk((size_t)1 << lg)), dim3(256), 0, c->stream, za);
@@ -1123,6 +1212,7 @@ struct glp_session {
             a.wires = dev_wires; a.sigmas = cc->dev_sigmas; a.k_is = cc->dev_k_is; a.zp = zp; a.dens = dens;
             for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
             a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
+            a.chal = nullptr; a.wires_stride = 0; a.zp_stride = 0;
             switch (nch) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<1>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<2>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
@@ -1130,9 +1220,9 @@ struct glp_session {
             default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<4>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
             }
             GLP_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_pp_block_tot, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks);
+            hipLaunchKernelGGL(k_pp_block_tot, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, (size_t)0);
             hipLaunchKernelGGL(k_pp_scan_tot, dim3(nch), dim3(256), 0, c->stream, tot, nblocks);
-            hipLaunchKernelGGL(k_pp_apply, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, nch, npp);
+            hipLaunchKernelGGL(k_pp_apply, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, nch, npp, (size_t)0);
             GLP_HIP(hipGetLastError());
         }
         GLP_TRY(batch_build(c, zp, BATCH_VALUES, nzp, lg, rb, (int)d.cap_height, &zb.b));
@@ -1158,10 +1248,14 @@ struct glp_session {
         GLP_TRY(tmp.get(&qV, (size_t)nch * Rq * n));
         GLP_TRY(tmp.get(&qc, (size_t)nch * Rq * n));
         QArgs a;
-        a.cs = cc->cs->lde; a.wl = wb.b->lde; a.zl = zb.b->lde; a.out = qv;
-        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; a.apow = dev_apow; a.k_ratio = cc->k_ratio;
-        for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
-        memcpy(a.pih, pih, 32);
+        QProof qp;
+        QBatch qbt;
+        memset(&qp, 0, sizeof(qp));
+        memset(&qbt, 0, sizeof(qbt));                    // pp == nullptr: one proof, described by qp
+        a.cs = cc->cs->lde; qp.wl = wb.b->lde; qp.zl = zb.b->lde; qp.out = qv;
+        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; qp.apow = dev_apow; a.k_ratio = cc->k_ratio;
+        for (u32 i = 0; i < nch; i++) { qp.betas[i] = betas[i]; qp.gammas[i] = gammas[i]; }
+        memcpy(qp.pih, pih, 32);
         const u64 WN = root_of_unity(lg + rb), gn = pow(GEN, (u64)n), wR = root_of_unity(rb);
         for (u32 rq = 0; rq < Rq; rq++) {
             const u32 r = rq * step;
@@ -1187,13 +1281,13 @@ struct glp_session {
             lg_.count = cc->light_count;
             for (u32 i = 0; i < 8; i++) lg_.gi[i] = cc->light_gi[i];
             switch (nch) {
-            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_); break;
+            case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_); break;
             case 2:
-                if (cc->light_count) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 0>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_);
+                if (cc->light_count) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 0>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_);
                 break;
-            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_); break;
-            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, lg_); break;
+            case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_); break;
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<4, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_); break;
             }
             GLP_HIP(hipGetLastError());
             if (a.gate_mode == 1) {
@@ -1203,11 +1297,11 @@ struct glp_session {
                     for (int i = 0; i < LIMB_SLOTS; i++) la.gi[i] = cc->limb_gi[i];
                     la.extra_count = cc->limb_extra_count;
                     for (int i = 0; i < 4; i++) la.extra_gi[i] = cc->limb_extra_gi[i];
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_limbs<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, la);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_limbs<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, la);
                     GLP_HIP(hipGetLastError());
                 }
                 for (u32 gi : cc->single_gates) {
-#define GLP_GATE_LAUNCH(T) case T: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_gate<2, T>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, gi); break;
+#define GLP_GATE_LAUNCH(T) case T: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_gate<2, T>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, gi); break;
                     switch (cc->gates[gi].type) {
                         GLP_GATE_LAUNCH(GLP_GATE_CONSTANT) GLP_GATE_LAUNCH(GLP_GATE_PUBLIC_INPUT) GLP_GATE_LAUNCH(GLP_GATE_ARITHMETIC)
                         GLP_GATE_LAUNCH(GLP_GATE_POSEIDON) GLP_GATE_LAUNCH(GLP_GATE_U32_INTERLEAVE) GLP_GATE_LAUNCH(GLP_GATE_UNINTERLEAVE_U32)
@@ -1313,6 +1407,8 @@ struct glp_session {
         a.apow = dev_ap; a.out = fv; a.red0 = red0; a.red1 = red1; a.zeta = zeta; a.zeta_next = zeta_next;
         a.shift_acc = e_pow(alpha, nch);
         a.w_n = root_of_unity(lg); a.g = GEN; a.lg = (u32)lg; a.rb = (u32)rb; a.nch = nch;
+        a.pp = nullptr; a.apow_stride = a.out_stride = 0;
+        for (int k = 0; k < 4; k++) a.lde_stride[k] = 0;
         hipLaunchKernelGGL(k_final_values, dim3(nblk(n)), dim3(256), 0, c->stream, a);
         GLP_HIP(hipGetLastError());
         GLP_TRY(intt_values_to_coeffs(c, fv, fcoef, 2, lg));
@@ -1339,9 +1435,10 @@ struct glp_session {
         GLP_TRY(lde_coeffs(c, cur, ly.vals, 2, lgcur, rb, shift));
         if (nleaves <= 8192)
             hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((nleaves + 15) / 16)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
-                               (u32)rb, ab);
+                               (u32)rb, ab, (size_t)0, (size_t)0);
         else
-            hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab);
+            hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab, (size_t)0,
+                               (size_t)0);
         GLP_HIP(hipGetLastError());
         GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height));
         cap.resize((size_t)capn * 4);
@@ -1359,7 +1456,7 @@ struct glp_session {
         u64 *nxt;
         const size_t nnew = ((size_t)1 << lgcur) >> ab;
         GLP_TRY(tmp.get(&nxt, 2 * nnew));
-        hipLaunchKernelGGL(k_fri_fold, dim3(nblk(nnew)), dim3(256), 0, c->stream, cur, nxt, beta, (u32)lgcur, ab);
+        hipLaunchKernelGGL(k_fri_fold, dim3(nblk(nnew)), dim3(256), 0, c->stream, cur, nxt, beta, (u32)lgcur, ab, (const u64 *)nullptr);
         GLP_HIP(hipGetLastError());
         cur = nxt; lgcur -= (int)ab;
         shift = pow(shift, (u64)1 << ab);
@@ -1410,7 +1507,7 @@ struct glp_session {
             const size_t nleaves = ((size_t)1 << ly.lgL) >> ly.ab;
             shift_bits += ly.ab;
             hipLaunchKernelGGL(k_fri_gather_leaf, dim3(nblk((size_t)nq * arity)), dim3(256), 0, c->stream, ly.vals, ly.lgL, (u32)rb,
-                               ly.ab, dev_idx, shift_bits, nq, dev_q + off, stride);
+                               ly.ab, dev_idx, shift_bits, nq, dev_q + off, stride, (size_t)0, (size_t)0);
             GLP_HIP(hipGetLastError());
             off += 2 * (size_t)arity;
             GLP_TRY(merkle_gather_paths(c, ly.dig, nleaves, (int)d.cap_height, dev_idx, nq, dev_q + off, stride, shift_bits));
@@ -1933,3 +2030,6 @@ int glp_prove(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, const ui
 }
 
 }  // extern "C"
+
+#include <stdlib.h>
+#include "prover_batch.inc"

@@ -117,6 +117,7 @@ void glp_ctx_destroy(glp_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     glp_ctx_stage_reset(c);
+    if (c->host_pool && c->host_pool_free) c->host_pool_free(c->host_pool);
     free_plans(c);
     c->trim();
     for (auto &kv : c->live) (void)hipFree(kv.first);

@@ -56,6 +56,8 @@ struct glp_ctx {
     std::map<int, glp::NttPlan *> ntt_plans;                       // key: log_n
     std::map<std::pair<std::pair<int, int>, u64>, glp::LdePlan *> lde_plans;  // key: ((log_n, rate_bits), shift)
     unsigned long long lde_clock = 0;                              // LRU stamps for lde_plans
+    void *host_pool = nullptr;           // HostPool of prover_batch.inc (host threads for the transcripts of a batch), made on first use
+    void (*host_pool_free)(void *) = nullptr;
     bool profiling = false;
     std::vector<glp::Stage> stages;
 

@@ -864,7 +864,8 @@ __global__ __launch_bounds__(256) void k_zeta_table(ZTArgs a) {
     a.zt[2 * p] = acc.a; a.zt[2 * p + 1] = acc.b;
 }
 // K7: partial sums of  sum_p coeffs[col][p] * zt[p]   grid = (OPEN_BLOCKS, ncols)
-constexpr int OPEN_BLOCKS = 32;
+constexpr int OPEN_BLOCKS = 32;      // at most; open_blocks(n) picks fewer for short polynomials (the stride is gridDim.x)
+inline u32 open_blocks(size_t n) { return (u32)std::max<size_t>(1, std::min<size_t>(OPEN_BLOCKS, n / 256)); }
 // blockIdx.z = proof of a batch: coefficients / table / partial sums advance by the given strides (0 = shared by all proofs)
 __global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *zt, u64 *partial, u32 lg, size_t coeffs_bstride,
                                                   size_t zt_bstride, size_t partial_bstride) {
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *
     AccLimb xa, xb;
     acc2_zero(xa); acc2_zero(xb);
     u32 terms = 0;
-    for (size_t p = (size_t)blockIdx.x * 256 + t; p < n; p += (size_t)OPEN_BLOCKS * 256) {
+    for (size_t p = (size_t)blockIdx.x * 256 + t; p < n; p += (size_t)gridDim.x * 256) {
         const u64 c = coeffs[(size_t)col * n + p];
         const u32 c0 = (u32)c & 0x3FFFFFu, c1 = (u32)(c >> 22) & 0x3FFFFFu, c2 = (u32)(c >> 44);
         acc2_fma(xa, c0, c1, c2, zt[2 * p]);
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(256) void k_open_dot(const u64 *coeffs, const u64 *
     sa[t] = a; sb[t] = b;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (t < s) { sa[t] = add(sa[t], sa[t + s]); sb[t] = add(sb[t], sb[t + s]); } __syncthreads(); }
-    if (t == 0) { partial[2 * ((size_t)col * OPEN_BLOCKS + blockIdx.x)] = sa[0]; partial[2 * ((size_t)col * OPEN_BLOCKS + blockIdx.x) + 1] = sb[0]; }
+    if (t == 0) { partial[2 * ((size_t)col * gridDim.x + blockIdx.x)] = sa[0]; partial[2 * ((size_t)col * gridDim.x + blockIdx.x) + 1] = sb[0]; }
 }
 
 // K8: values of the FRI batch polynomial on the coset plane 0 (x_q = g w_n^q):
@@ -1056,24 +1057,38 @@ __global__ __launch_bounds__(256) void k_pow(PowArgs a) {
     if (a.bits == 0 || (s[7] >> (64 - a.bits)) == 0) atomicMin(a.best, (unsigned long long)cand);
 }
 
-// K10 for a batch: blockIdx.y = proof, each with its own sponge state st_b[proof][12] and input position pos_b[proof].  The
-// workgroups of one proof sweep the candidates in increasing order, gridDim.x * 256 at a time, and stop as soon as the
-// smallest witness found so far (best[proof]) lies below everything they would still test: the result is the smallest
-// witness regardless of scheduling, and every wave leaves the loop (a witness exists below 2^40 with overwhelming probability;
-// the sweep is cut there in any case).
-__global__ __launch_bounds__(256) void k_pow_batch(const u64 *st_b, const u32 *pos_b, u32 bits, unsigned long long *best) {
-    const u32 pk = blockIdx.y;
-    u64 st[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = st_b[(size_t)pk * 12 + i];
-    const u32 pos = pos_b[pk];
-    volatile unsigned long long *mine = best + pk;
-    for (u64 base = (u64)blockIdx.x * 256; base < (1ull << 40); base += (u64)gridDim.x * 256) {
-        if (*mine <= base) break;                    // something smaller than this whole chunk is already known
-        const u64 cand = base + threadIdx.x;
+// K10 for a batch of K proofs, each with its own sponge state st_b[proof][12] and input position pos_b[proof].  Workgroups
+// are persistent: a workgroup takes the next 256 candidates of a proof from that proof's counter (next[proof], handed out
+// in increasing order), tests them, and records the smallest hit in best[proof]; it leaves a proof once a hit below its next
+// chunk is known and moves on to the next unfinished proof, so the long tail of one unlucky search is shared by the whole
+// GPU instead of idling it.  Every chunk below the final best[proof] was handed out and completed before the kernel ends,
+// hence the result is the smallest witness regardless of scheduling.  Termination: a proof is finished once best <= next
+// (a witness exists below 2^40 with overwhelming probability; the hand-out stops there in any case), and a workgroup exits
+// after one full pass over the proofs finds none unfinished.
+__global__ __launch_bounds__(256) void k_pow_batch(const u64 *st_b, const u32 *pos_b, u32 bits, unsigned long long *best,
+                                                   unsigned long long *next, u32 K) {
+    __shared__ unsigned long long sh_base;
+    u32 pk = blockIdx.x % K, idle = 0;
+    while (idle < K) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long b = ~0ull;
+            const unsigned long long cur = *(volatile unsigned long long *)(best + pk);
+            if (*(volatile unsigned long long *)(next + pk) < cur) {
+                b = atomicAdd(next + pk, 256ull);
+                if (b >= cur || b >= (1ull << 40)) b = ~0ull;       // nothing below the known witness (or the cap) is left
+            }
+            sh_base = b;
+        }
+        __syncthreads();
+        const unsigned long long base = sh_base;
+        if (base == ~0ull) { pk = pk + 1 == K ? 0 : pk + 1; idle++; continue; }
+        idle = 0;
         u64 s[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = st[i];
+        for (int i = 0; i < 12; i++) s[i] = st_b[(size_t)pk * 12 + i];
+        const u32 pos = pos_b[pk];
+        const u64 cand = base + threadIdx.x;
         for (u32 i = 0; i < 8; i++) if (i == pos) s[i] = cand;      // candidates stay far below p
         pos::permute(s);
         if (bits == 0 || (s[7] >> (64 - bits)) == 0) atomicMin(best + pk, (unsigned long long)cand);
@@ -1116,17 +1131,17 @@ int batch_cap_host(glp_ctx *c, const glp_batch *b, std::vector<u64> &cap) {
 }
 // evaluate every polynomial of a batch at z: launch only; partial sums land in dev_partial [ncols][OPEN_BLOCKS][2]
 int open_batch_launch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial) {
-    dim3 g(OPEN_BLOCKS, b->ncols);
+    dim3 g(open_blocks((size_t)1 << b->lg), b->ncols);
     hipLaunchKernelGGL(k_open_dot, g, dim3(256), 0, c->stream, b->coeffs, dev_zt, dev_partial, (u32)b->lg, (size_t)0, (size_t)0, (size_t)0);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }
 // host side of the same: fold the OPEN_BLOCKS partial sums of each column
-void open_batch_finish(const u64 *h, u32 ncols, std::vector<ext2> &out) {
+void open_batch_finish(const u64 *h, u32 ncols, u32 nob, std::vector<ext2> &out) {
     out.resize(ncols);
     for (u32 col = 0; col < ncols; col++) {
         u64 a = 0, bb = 0;
-        for (int k = 0; k < OPEN_BLOCKS; k++) { a = add(a, h[2 * ((size_t)col * OPEN_BLOCKS + k)]); bb = add(bb, h[2 * ((size_t)col * OPEN_BLOCKS + k) + 1]); }
+        for (u32 k = 0; k < nob; k++) { a = add(a, h[2 * ((size_t)col * nob + k)]); bb = add(bb, h[2 * ((size_t)col * nob + k) + 1]); }
         out[col] = e_make(a, bb);
     }
 }
@@ -1351,8 +1366,9 @@ struct glp_session {
         // five evaluations (four batches at zeta, the Z batch at g zeta) queued back to back, one copy back
         u64 *zt, *partial;
         GLP_TRY(tmp.get(&zt, 2 * n));
+        const u32 nob = open_blocks(n);
         size_t poff[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < 5; k++) poff[k + 1] = poff[k] + (size_t)(k < 4 ? ob[k] : zb.b)->ncols * OPEN_BLOCKS * 2;
+        for (int k = 0; k < 5; k++) poff[k + 1] = poff[k] + (size_t)(k < 4 ? ob[k] : zb.b)->ncols * nob * 2;
         GLP_TRY(tmp.get(&partial, poff[5]));
         GLP_TRY(zeta_table(c, zeta, lg, zt));
         for (int k = 0; k < 4; k++) GLP_TRY(open_batch_launch(c, ob[k], zt, partial + poff[k]));
@@ -1360,9 +1376,9 @@ struct glp_session {
         GLP_TRY(open_batch_launch(c, zb.b, zt, partial + poff[4]));
         std::vector<u64> hp(poff[5]);
         GLP_TRY(d2h(c, hp.data(), partial, hp.size() * 8));
-        for (int k = 0; k < 4; k++) open_batch_finish(hp.data() + poff[k], ob[k]->ncols, open[k]);
+        for (int k = 0; k < 4; k++) open_batch_finish(hp.data() + poff[k], ob[k]->ncols, nob, open[k]);
         std::vector<ext2> all;
-        open_batch_finish(hp.data() + poff[4], zb.b->ncols, all);
+        open_batch_finish(hp.data() + poff[4], zb.b->ncols, nob, all);
         zs_next.assign(all.begin(), all.begin() + nch);
     }
         {

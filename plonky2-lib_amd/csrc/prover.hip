@@ -617,7 +617,9 @@ __device__ __forceinline__ void gate_contrib(const QArgs &a, const QProof &p, co
 }
 
 // Gates that ride along with another launch (indices into the gate table)
-struct LightArgs { u32 count; u32 gi[8]; };
+// arith_ops != 0: gate arith_gi is an ArithmeticGate whose first arith_ops operations read only routed wires; k_quotient
+// evaluates them from the wire values its permutation loop has in registers anyway (no second read of those planes).
+struct LightArgs { u32 count; u32 gi[8]; u32 arith_gi, arith_ops; };
 // The HBM-bound gate types (Constant, PublicInput, Arithmetic, BaseSum, RandomAccess), evaluated one after the other
 template <int NCH>
 __device__ __forceinline__ void light_gates(const QArgs &a, const QProof &p, const LightArgs &la, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
@@ -658,6 +660,15 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
     }
     u64 bkx[MAXCH];                                    // beta_c k_j x for the next wire j (k_ratio path)
     _Pragma("unroll") for (int c = 0; c < NCH; c++) bkx[c] = mul_nc(p.betas[c], x);
+    const u32 k0 = nch + nch * nchunks;
+    // ArithmeticGate riding on the permutation loop's wire loads (GATES == 2 only)
+    const u32 ar_ops = GATES == 2 ? la.arith_ops : 0;
+    AccLimb gar[MAXCH];
+    u64 ar_c0 = 0, ar_c1 = 0;
+    if (GATES == 2) {
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(gar[c]);
+        if (ar_ops) { ar_c0 = a.cs[(size_t)a.nsel * N + slot]; ar_c1 = a.cs[(size_t)(a.nsel + 1) * N + slot]; }
+    }
     for (u32 chunk = 0; chunk < nchunks; chunk++) {
         u64 num[MAXCH], den[MAXCH];
         _Pragma("unroll") for (int c = 0; c < NCH; c++) { num[c] = 1; den[c] = 1; }
@@ -667,6 +678,16 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
 #pragma unroll
             for (int t = 0; t < 8; t++)
                 if (jb + t < j1) { w8[t] = p.wl[(size_t)(jb + t) * N + slot]; s8[t] = a.cs[(size_t)(a.nc + jb + t) * N + slot]; }
+            if (GATES == 2 && ar_ops) {                // jb is a multiple of 4 here (the host checks qdf % 4 == 0)
+#pragma unroll
+                for (int t = 0; t < 8; t += 4)
+                    if (jb + t + 3 < j1 && (jb + t) / 4 < ar_ops) {
+                        const u32 i = (jb + t) / 4;
+                        const u64 v = sub(w8[t + 3], add(mul(mul(w8[t], w8[t + 1]), ar_c0), mul(w8[t + 2], ar_c1)));
+                        const u32 v0 = (u32)v & 0x3FFFFFu, v1 = (u32)(v >> 22) & 0x3FFFFFu, v2 = (u32)(v >> 44);
+                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(gar[c2], v0, v1, v2, p.apow[c2 * nt + k0 + i]);
+                    }
+            }
 #pragma unroll
             for (int t = 0; t < 8; t++)
                 if (jb + t < j1) {
@@ -694,7 +715,10 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
         }
     }
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
-    const u32 k0 = nch + nch * nchunks;
+    if (GATES == 2 && ar_ops) {
+        const u64 filter = gate_filter(a, a.gates[la.arith_gi], N, slot);
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(gar[c])));
+    }
     if constexpr (GATES == 1) {                        // monolithic: every gate here
         for (u32 gi = 0; gi < a.num_gates; gi++) {
             const DevGate g = a.gates[gi];
@@ -1293,12 +1317,12 @@ struct glp_session {
             hipLaunchKernelGGL(k_l0_table, dim3(nblk(n)), dim3(256), 0, c->stream, a, l0t, Rq);
             GLP_HIP(hipGetLastError());
             LightArgs lg_;
-            lg_.count = cc->light_count;
+            lg_.count = cc->light_count; lg_.arith_gi = cc->arith_gi; lg_.arith_ops = cc->arith_ops;
             for (u32 i = 0; i < 8; i++) lg_.gi[i] = cc->light_gi[i];
             switch (nch) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<1, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_); break;
             case 2:
-                if (cc->light_count) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_);
+                if (cc->light_count || cc->arith_ops) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<2, 0>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_);
                 break;
             case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient<3, 1>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, lg_); break;
@@ -1681,6 +1705,9 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
                     for (u32 j = 0; j < 16; j++)
                         put(s, g.p0 + 16 * i + j, j, 17 * i + 1 + j, j == 15, 17 * i, i);
             }
+        } else if (g.type == GLP_GATE_ARITHMETIC && cc->arith_ops == 0 && 4 * g.p0 <= d.num_routed_wires && d.quotient_degree_factor % 4 == 0 &&
+                   d.num_selectors + 2 <= d.num_constants) {
+            cc->arith_gi = gi; cc->arith_ops = g.p0;      // evaluated inside the permutation loop of k_quotient
         } else if (light && cc->light_count < 8) {
             cc->light_gi[cc->light_count++] = gi;
         } else if (g.type != GLP_GATE_NOOP) {

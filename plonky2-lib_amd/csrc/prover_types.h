@@ -36,6 +36,7 @@ struct glp_circuit {
     u64 *dev_limb_desc = nullptr;  // [num_wires][4] column program of k_quotient_limbs
     u32 limb_count = 0, limb_gi[4] = {0, 0, 0, 0}, limb_jlo = 0, limb_jhi = 0;
     u32 limb_extra_count = 0, limb_extra_gi[4] = {0, 0, 0, 0};
+    u32 arith_gi = 0, arith_ops = 0;   // ArithmeticGate evaluated inside the permutation loop (0 ops: none)
     u32 light_count = 0, light_gi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<u32> single_gates; // gates that keep a launch of their own
     glp_batch *cs = nullptr;       // constants_sigmas_commitment

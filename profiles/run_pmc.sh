@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash profiles/run_pmc.sh <tag>
+# Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: gfx950 cannot hold both in one pass) of one proof of the headline
+# bench, combined by pmc_summary.py into per-dispatch HBM bytes (gfx950 correction documented there).
+set -e
+TAG=$1
+ROOT=$(pwd)
+export TMPDIR=/tmp
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  OUT=$ROOT/gpurun_out/pmc_${TAG}_$C
+  mkdir -p $OUT
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --steps 1 --warmup 0 > /dev/null 2> $ROOT/gpurun_out/pmc_${TAG}_$C.err
+done
+cd $ROOT
+F=$(find gpurun_out/pmc_${TAG}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+W=$(find gpurun_out/pmc_${TAG}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 profiles/pmc_summary.py $F $W gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.txt
+find gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE -name "*.csv" -size +3M -delete
+grep -E "k_quotient|k_l0|k_lde_contig16|k_leaf_hash" gpurun_out/${TAG}_pmc_traffic.txt | head -20

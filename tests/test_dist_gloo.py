@@ -51,3 +51,17 @@ def test_single_rank_needs_no_process_group():
     g = gdist.Group()
     assert gdist.timed_steps(g, lambda: None, 2, 1) >= 0.0
     assert list(gdist.proofs_for_rank(5, 0, 1)) == [0, 1, 2, 3, 4]
+
+
+def test_bench_gpus_flag_is_honoured_without_a_launcher():
+    """`python bench.py --gpus N` (no torch.distributed.run around it) must start N ranks itself or fail loudly -- never run one
+    rank and report n_gpus = 1.  Without N visible GPUs that is an error naming the flag."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"], capture_output=True, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 3:
+        assert r.returncode != 0 and "--gpus 3" in r.stderr and "visible" in r.stderr
+    assert '"n_gpus": 1' not in r.stdout

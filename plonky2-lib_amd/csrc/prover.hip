@@ -1154,8 +1154,8 @@ int batch_cap_host(glp_ctx *c, const glp_batch *b, std::vector<u64> &cap) {
     return d2h(c, cap.data(), b->digests + 4 * merkle_cap_offset(N, b->cap_height), cap.size() * 8);
 }
 // evaluate every polynomial of a batch at z: launch only; partial sums land in dev_partial [ncols][OPEN_BLOCKS][2]
-int open_batch_launch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial) {
-    dim3 g(open_blocks((size_t)1 << b->lg), b->ncols);
+int open_batch_launch(glp_ctx *c, const glp_batch *b, const u64 *dev_zt, u64 *dev_partial, u32 first_cols = 0 /* 0: all */) {
+    dim3 g(open_blocks((size_t)1 << b->lg), first_cols ? first_cols : b->ncols);
     hipLaunchKernelGGL(k_open_dot, g, dim3(256), 0, c->stream, b->coeffs, dev_zt, dev_partial, (u32)b->lg, (size_t)0, (size_t)0, (size_t)0);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
@@ -1386,23 +1386,23 @@ struct glp_session {
         zeta_next = e_scale(zeta, root_of_unity(lg));
         ob[0] = cc->cs; ob[1] = wb.b; ob[2] = zb.b; ob[3] = qb.b;
         {
-        StageScope st(c, "openings", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3] + nzp));
+        StageScope st(c, "openings", 8.0 * n * (L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3] + nch));
         // five evaluations (four batches at zeta, the Z batch at g zeta) queued back to back, one copy back
         u64 *zt, *partial;
         GLP_TRY(tmp.get(&zt, 2 * n));
         const u32 nob = open_blocks(n);
         size_t poff[6] = {0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < 5; k++) poff[k + 1] = poff[k] + (size_t)(k < 4 ? ob[k] : zb.b)->ncols * nob * 2;
+        for (int k = 0; k < 5; k++) poff[k + 1] = poff[k] + (size_t)(k < 4 ? ob[k]->ncols : nch) * nob * 2;    // at g zeta: only the Z columns
         GLP_TRY(tmp.get(&partial, poff[5]));
         GLP_TRY(zeta_table(c, zeta, lg, zt));
         for (int k = 0; k < 4; k++) GLP_TRY(open_batch_launch(c, ob[k], zt, partial + poff[k]));
         GLP_TRY(zeta_table(c, zeta_next, lg, zt));
-        GLP_TRY(open_batch_launch(c, zb.b, zt, partial + poff[4]));
+        GLP_TRY(open_batch_launch(c, zb.b, zt, partial + poff[4], nch));
         std::vector<u64> hp(poff[5]);
         GLP_TRY(d2h(c, hp.data(), partial, hp.size() * 8));
         for (int k = 0; k < 4; k++) open_batch_finish(hp.data() + poff[k], ob[k]->ncols, nob, open[k]);
         std::vector<ext2> all;
-        open_batch_finish(hp.data() + poff[4], zb.b->ncols, nob, all);
+        open_batch_finish(hp.data() + poff[4], nch, nob, all);
         zs_next.assign(all.begin(), all.begin() + nch);
     }
         {

@@ -1,0 +1,44 @@
+"""bench.py contract checks on a GPU box: `--gpus N` without a launcher starts N ranks (here two gloo ranks sharing the one
+GPU of the test box, small trace), every rank proves a different witness and verifies its own proof, rank 0 prints ONE JSON
+line with n_gpus = N."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_two_ranks_started_by_bench_itself():
+    d = _run(["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--log-n", "12", "--steps", "2", "--warmup", "1",
+              "--no-variants", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["verified"] is True and d["steps"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]      # whole-job throughput
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None
+
+
+def test_single_rank_line_has_roofline_verified_and_variants():
+    d = _run(["--log-n", "13", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 1 and d["verified"] is True
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    v = d["variants"]
+    assert v["witness_from_host_memory"]["same_proof_as_resident"] is True
+    assert v["gpu_witness_fill_advice_columns"]["same_proof_after_fill"] is True
+
+
+def test_zkdsa_batch_workload_line():
+    d = _run(["--workload", "zkdsa-batch", "--batch", "64", "--sub-batch", "32", "--threads", "2", "--steps", "1", "--warmup", "1"])
+    assert d["verified"] is True and d["value"] > 0 and "glp_prove_batch" in d["config"]["workload"]

@@ -55,11 +55,18 @@ SHAPES = (("wires", 136), ("zs_partial_products", 20), ("quotient_chunks", 16))
 BATCH_STAGES = ("intt", "copy_coeffs", "bitrev_coeffs", "lde", "merkle_leaves", "merkle_levels")
 
 
+def pmc_traffic_file():
+    """The newest committed PMC summary (profiles/rNN_pmc_traffic.json, made by profiles/run_pmc.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    return files[-1] if files else os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+
+
 def pmc_traffic(stage_key, log_n):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate
     FETCH_SIZE / WRITE_SIZE runs of this same bench, corrected as profiles/pmc_summary.py documents).
     Only valid for the configuration the passes were taken on (2^20 rows)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = pmc_traffic_file()
     kernel = {"merkle_leaves": "k_leaf_hash_lde", "lde": "k_strided16<false>", "quotient_eval": "k_quotient"}.get(
         stage_key.split("/")[-1])
     if log_n != 20 or kernel is None or not os.path.exists(path):
@@ -405,14 +412,14 @@ def main():
                 "bound": "hbm",
                 "kernel": dom,
                 "kernel_symbol": {"merkle_leaves": "glp::k_leaf_hash_lde", "lde": "glp::k_lde_contig16 + glp::k_strided16<false>",
-                                  "quotient_eval": "k_quotient<2,false> + k_quotient_gate<2,T>"}.get(dom.split("/")[-1]),
+                                  "quotient_eval": "k_quotient<2,2> + k_quotient_limbs<2>"}.get(dom.split("/")[-1]),
                 "launch_ms": stage_out[dom]["ms"],
                 "achieved": ach,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (ach / HBM_PEAK_GBS) if ach else None,
                 "traffic": pmc_traffic(dom, lg),
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" % os.path.basename(pmc_traffic_file()),
                 "algorithmic_bytes": stages[dom][2],
                 "note": "the dominant kernel (Poseidon leaf hashing) is VALU-bound, not HBM-bound: see DESIGN.md; "
                         "HBM fraction reported as the contract asks",

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Randomised parity campaign (a tool, not collected by pytest): random CircuitConfig / FriConfig fields, trace sizes,
 gate mixes and public inputs; for each case the HIP library's proof must equal the CPU oracle's word for word, both
-verifiers must accept it and reject a tampered copy.  Usage: python tests/fuzz_parity.py [cases] [seed]   (FUZZ_MIN_LG / FUZZ_MAX_LG bound the trace length, default 5..11)"""
+verifiers must accept it and reject a tampered copy; (round 2) the row-local witness generators on the GPU must rebuild a scrambled
+witness exactly as the oracle's do, and with two challenges a two-proof glp_prove_batch must return the single proofs.  Usage: python tests/fuzz_parity.py [cases] [seed]   (FUZZ_MIN_LG / FUZZ_MAX_LG bound the trace length, default 5..11)"""
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 
 import plonky2_lib_amd as glp
@@ -35,7 +37,7 @@ def random_case(rng):
     family = "arith"
     seed = int(rng.integers(1, 1 << 30))
     if qdf >= 8 and rng.random() < 0.75:       # PoseidonGate (degree 7) and the reference's u32 gates need quotient degree factor 8
-        family = str(rng.choice(["poseidon_chain", "u32", "zkdsa", "keccak"]))
+        family = str(rng.choice(["poseidon_chain", "u32", "zkdsa", "keccak", "smt"]))
     if family == "poseidon_chain":
         desc = synth.poseidon_chain_circuit(max(lg, 5), config, seed=seed)
     elif family == "u32":
@@ -44,6 +46,8 @@ def random_case(rng):
         desc = synth.zkdsa_circuit(3, config, seed=seed)
     elif family == "keccak":
         desc = synth.keccak_shape_circuit(max(lg, 6), seed=seed)
+    elif family == "smt":
+        desc = synth.smt_shape_circuit(max(lg, 5), config, seed=seed)
     else:
         desc = synth.arith_circuit(lg, config, seed=seed, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi) if npi else None,
                                    ecdsa_gate_rows=gate_rows, ecdsa_gate_subset=subset)
@@ -70,6 +74,20 @@ def main():
         pos = int(rng.integers(0, len(bad)))
         bad[pos] = (int(bad[pos]) + 1) % glp.P
         ok = ok and (not gc.verify(bad)) and oc.verify(bad) != 0
+        # row-local witness generation: scramble what the generators derive, regenerate on the GPU and with the oracle
+        from test_oracle_witness import scramble_derived
+        w, _ = scramble_derived(desc, rng)
+        w = np.ascontiguousarray(w)
+        dptr = ctx.dev_alloc(w.nbytes)
+        ctx.dev_upload(dptr, w)
+        gc.witness_fill(dptr)
+        back = np.empty_like(w)
+        ctx.dev_download(dptr, back)
+        ctx.dev_free(dptr)
+        ok = ok and (back == oc.witness_fill(w)).all()
+        if desc.num_challenges == 2:             # the batch path: two proofs (the witness and its regenerated twin) in lock step
+            both = gc.prove_batch(np.stack([desc.wires, back]), np.stack([desc.public_inputs, desc.public_inputs]) if len(desc.public_inputs) else None)
+            ok = ok and (both[0] == got).all() and (both[1] == gc.prove(wires=back)).all()
         print("case %3d %s  %s  (%.0f s)" % (i, "ok  " if ok else "FAIL", info, time.time() - t0), flush=True)
         if not ok:
             if rc == 0 and not (got == ref).all():

@@ -212,3 +212,23 @@ def test_errors(ctx):
     with pytest.raises(glp.GlpError) as e:
         glp.Batch._make_dev(ctx, "glp_batch_from_values_device", 8, 1, 25, 3, 4)      # > 2^24 rows
     assert e.value.code == -3
+
+
+def test_lde_plan_cache_is_bounded_and_stays_correct(ctx, oracle):
+    """glp_lde keys its coset tables by the caller's shift (unbounded growth).  More distinct shifts than the cache
+    holds: results stay right before, across and after evictions, including a shift whose plan was evicted and rebuilt."""
+    rng = np.random.default_rng(60)
+    c = oracle.rand_field(rng, (1, 1 << 13))
+    shifts = [int(x) for x in oracle.rand_field(rng, (70,)) if int(x) != 0]
+    first = ctx.lde(c, 2, shifts[0])
+    assert (first[0] == oracle.lde(c[0], 2, shifts[0])).all()
+    for s in shifts[1:]:
+        got = ctx.lde(c, 2, s)
+        assert got[0][123] == oracle.lde(c[0], 2, s)[123]
+    again = ctx.lde(c, 2, shifts[0])                 # evicted by now (70 > LDE_PLAN_CACHE_MAX = 48): rebuilt
+    assert (again == first).all()
+    big = oracle.rand_field(rng, (1, 1 << 21))        # a three-pass plan pins its inner plan while others are evicted around it
+    assert (ctx.lde(big, 1, 7)[0][::4097] == oracle.lde(big[0], 1, 7)[::4097]).all()
+    for s in shifts[:50]:
+        ctx.lde(c, 1, s)
+    assert (ctx.lde(big, 1, 7)[0][::4097] == oracle.lde(big[0], 1, 7)[::4097]).all()

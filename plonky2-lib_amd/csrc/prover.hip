@@ -256,6 +256,26 @@ __device__ __forceinline__ u64 acc2_reduce(const AccLimb &a) {    // canonical
     return acc_reduce(w);
 }
 
+// The same carry-free scheme with the roles swapped, for the quotient: the multiplier alpha^k comes from a table the host
+// cuts into 22-bit limbs once per proof, so a constraint value enters as its two 32-bit halves -- the registers it already
+// lives in -- instead of being cut into three limbs per term (5 shift / mask slots per constraint, 620 constraints per point).
+struct AccHL { u64 b00, b01, b02, b10, b11, b12; };       // b[i][j]: half i of v (bits 32 i ..) times limb j of m (bits 22 j ..)
+__device__ __forceinline__ void acc3_zero(AccHL &a) { a.b00 = a.b01 = a.b02 = a.b10 = a.b11 = a.b12 = 0; }
+__device__ __forceinline__ void acc3_fma(AccHL &a, u64 v, const u64 *ml /* {m0 | m1 << 32, m2} */) {
+    const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
+    const u64 w0 = ml[0], w1 = ml[1];
+    const u32 m0 = (u32)w0, m1 = (u32)(w0 >> 32), m2 = (u32)w1;
+    a.b00 += (u64)vlo * m0; a.b01 += (u64)vlo * m1; a.b02 += (u64)vlo * m2;
+    a.b10 += (u64)vhi * m0; a.b11 += (u64)vhi * m1; a.b12 += (u64)vhi * m2;
+}
+__device__ __forceinline__ u64 acc3_reduce(const AccHL &a) {      // canonical
+    Acc160 w;
+    acc_zero(w);
+    acc_add_shifted<0>(w, a.b00); acc_add_shifted<22>(w, a.b01); acc_add_shifted<32>(w, a.b10);
+    acc_add_shifted<44>(w, a.b02); acc_add_shifted<54>(w, a.b11); acc_add_shifted<76>(w, a.b12);
+    return acc_reduce(w);
+}
+
 struct QArgs {                      // per circuit and FRI domain: the same for every proof of a batch
     const u64 *cs;                  // coset-major LDE [ncols][R][n] of constants ++ sigmas
     const DevGate *gates;
@@ -270,6 +290,7 @@ struct QProof {                     // per proof
     const u64 *wl, *zl;             // coset-major LDEs of the wires and of Z ++ partial products
     u64 *out;                       // [nch][Rq][n]
     const u64 *apow;                // [nch][nterms] powers of the alphas
+    const u64 *apl;                 // the same powers as 22-bit limbs, two words per power: m0 | m1 << 32, m2 (AccHL)
     u64 betas[MAXCH], gammas[MAXCH], pih[4];
 };
 // many-proofs batch (glp_prove_batch): blockIdx.z = proof; arrays advance by a stride per proof, challenges and the public-input
@@ -280,7 +301,7 @@ __device__ __forceinline__ QProof q_proof(const QProof &p0, const QBatch &b) {
     QProof p = p0;
     if (b.pp) {
         const size_t k = blockIdx.z;
-        p.wl += k * b.wl_stride; p.zl += k * b.zl_stride; p.out += k * b.out_stride; p.apow += k * b.apow_stride;
+        p.wl += k * b.wl_stride; p.zl += k * b.zl_stride; p.out += k * b.out_stride; p.apow += k * b.apow_stride; p.apl += 2 * k * b.apow_stride;
         const u64 *q = b.pp + k * 3 * MAXCH;
         _Pragma("unroll") for (int c = 0; c < MAXCH; c++) { p.betas[c] = q[c]; p.gammas[c] = q[MAXCH + c]; p.pih[c] = q[2 * MAXCH + c]; }
     }
@@ -319,17 +340,16 @@ __device__ __forceinline__ u64 gate_filter(const QArgs &a, const DevGate &g, siz
 // HEAD_ONLY (the four base-4 limb gates of plonky2_u32): skip the limb columns -- their range products, base-4 sums and the
 // sum-equals-wire constraints -- which k_quotient_limbs evaluates for all fused gates from ONE read of the wire planes.
 template <int NCH, int TYPE, bool HEAD_ONLY = false>
-__device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, const DevGate &g, size_t N, size_t slot, u32 k0, AccLimb (&ga)[MAXCH]) {
+__device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, const DevGate &g, size_t N, size_t slot, u32 k0, AccHL (&ga)[MAXCH]) {
     const u32 nt = a.nterms;
     const u64 *W = p.wl + slot;                       // wire j  -> W[j * N]
     const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
     {
-        const u64 *ap = p.apow + k0;
+        const u64 *ap = p.apl + 2 * (size_t)k0;
 #define EMIT(k, v)                                                                     \
     do {                                                                               \
         const u64 _v = (v);                                                            \
-        const u32 _v0 = (u32)_v & 0x3FFFFFu, _v1 = (u32)(_v >> 22) & 0x3FFFFFu, _v2 = (u32)(_v >> 44);   \
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(ga[c2], _v0, _v1, _v2, ap[c2 * nt + (k)]);   \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[c2], _v, ap + 2 * ((size_t)c2 * nt + (k)));   \
     } while (0)
 // Base-4 limb columns LIMBS[j*N], j = COUNT-1 .. 0: eight loads are issued before their values are used (the gate
 // loops have run-time bounds, so the compiler cannot software-pipeline them itself).  Constraint index KIDX may use _j.
@@ -610,10 +630,10 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
 template <int NCH, int TYPE>
 __device__ __forceinline__ void gate_contrib(const QArgs &a, const QProof &p, const DevGate &g, size_t N, size_t slot, u32 k0, u64 (&acc)[MAXCH]) {
     const u64 filter = gate_filter(a, g, N, slot);
-    AccLimb ga[MAXCH];
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[c]);
+    AccHL ga[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc3_zero(ga[c]);
     gate_terms<NCH, TYPE, false>(a, p, g, N, slot, k0, ga);
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[c])));
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc3_reduce(ga[c])));
 }
 
 // Gates that ride along with another launch (indices into the gate table)
@@ -663,10 +683,10 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
     const u32 k0 = nch + nch * nchunks;
     // ArithmeticGate riding on the permutation loop's wire loads (GATES == 2 only)
     const u32 ar_ops = GATES == 2 ? la.arith_ops : 0;
-    AccLimb gar[MAXCH];
+    AccHL gar[MAXCH];
     u64 ar_c0 = 0, ar_c1 = 0;
     if (GATES == 2) {
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(gar[c]);
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc3_zero(gar[c]);
         if (ar_ops) { ar_c0 = a.cs[(size_t)a.nsel * N + slot]; ar_c1 = a.cs[(size_t)(a.nsel + 1) * N + slot]; }
     }
     for (u32 chunk = 0; chunk < nchunks; chunk++) {
@@ -684,8 +704,7 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
                     if (jb + t + 3 < j1 && (jb + t) / 4 < ar_ops) {
                         const u32 i = (jb + t) / 4;
                         const u64 v = sub(w8[t + 3], add(mul(mul(w8[t], w8[t + 1]), ar_c0), mul(w8[t + 2], ar_c1)));
-                        const u32 v0 = (u32)v & 0x3FFFFFu, v1 = (u32)(v >> 22) & 0x3FFFFFu, v2 = (u32)(v >> 44);
-                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(gar[c2], v0, v1, v2, p.apow[c2 * nt + k0 + i]);
+                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(gar[c2], v, p.apl + 2 * ((size_t)c2 * nt + k0 + i));
                     }
             }
 #pragma unroll
@@ -717,7 +736,7 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = acc_reduce(pa[c]);
     if (GATES == 2 && ar_ops) {
         const u64 filter = gate_filter(a, a.gates[la.arith_gi], N, slot);
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(gar[c])));
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc3_reduce(gar[c])));
     }
     if constexpr (GATES == 1) {                        // monolithic: every gate here
         for (u32 gi = 0; gi < a.num_gates; gi++) {
@@ -777,12 +796,12 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
     const size_t slot = (size_t)r * n + q;
     const u32 k0 = (u32)NCH + (u32)NCH * (a.npp + 1), nt = a.nterms;
     const u64 *W = p.wl + slot;
-    const u64 *ap = p.apow + k0;
-    AccLimb ga[LIMB_SLOTS][MAXCH];
+    const u64 *ap = p.apl + 2 * (size_t)k0;
+    AccHL ga[LIMB_SLOTS][MAXCH];
     Base4Sum bs[LIMB_SLOTS];
     _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
         b4_zero(bs[s]);
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc2_zero(ga[s][c]);
+        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc3_zero(ga[s][c]);
     }
     // heads
     _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
@@ -799,8 +818,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
 #define LIMB_EMIT(S, K, V)                                                                                     \
     do {                                                                                                       \
         const u64 _v = (V);                                                                                    \
-        const u32 _v0 = (u32)_v & 0x3FFFFFu, _v1 = (u32)(_v >> 22) & 0x3FFFFFu, _v2 = (u32)(_v >> 44);         \
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(ga[S][c2], _v0, _v1, _v2, ap[c2 * nt + (K)]);   \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[S][c2], _v, ap + 2 * ((size_t)c2 * nt + (K)));   \
     } while (0)
     for (u32 j0 = la.jlo; j0 <= la.jhi; j0 += 8) {
         u64 lv[8];
@@ -809,12 +827,11 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
             const u64 v = lv[t];
             const u64 *dj = la.desc + (size_t)(j0 + t) * LIMB_SLOTS;
             const u64 rp = range_product(v, 4);
-            const u32 r0 = (u32)rp & 0x3FFFFFu, r1 = (u32)(rp >> 22) & 0x3FFFFFu, r2 = (u32)(rp >> 44);
             _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
                 const u64 d = dj[s];
                 if (d & 1) {
                     const u32 kl = (u32)(d >> 6) & 0x3FFu;
-                    _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc2_fma(ga[s][c2], r0, r1, r2, ap[c2 * nt + kl]);
+                    _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[s][c2], rp, ap + 2 * ((size_t)c2 * nt + kl));
                     b4_add(bs[s], v, (u32)(d >> 1) & 15u);
                     if (d & 32) {
                         const u32 kf = (u32)(d >> 16) & 0x3FFu, ref = (u32)(d >> 26) & 0xFFu;
@@ -831,7 +848,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
     _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
         if ((u32)s < la.count) {
             const u64 filter = gate_filter(a, a.gates[la.gi[s]], N, slot);
-            _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc2_reduce(ga[s][c])));
+            _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc3_reduce(ga[s][c])));
         }
     }
     for (u32 t = 0; t < la.extra_count; t++) {             // after the limb accumulators are dead (register budget)
@@ -1278,8 +1295,18 @@ struct glp_session {
         while ((1u << qdb) < qdf) qdb++;
         const u32 Rq = 1u << qdb, step = 1u << (rb - qdb);
         const u32 nchunks = npp + 1, nterms = nch + nch * nchunks + d.num_gate_constraints;
-        std::vector<u64> apow((size_t)nch * nterms);
-        for (u32 i = 0; i < nch; i++) { u64 x = 1; for (u32 k = 0; k < nterms; k++) { apow[(size_t)i * nterms + k] = x; x = mul(x, alphas[i]); } }
+        // alpha powers twice: whole (permutation terms) and as 22-bit limbs (gate constraints, AccHL): [3][nch * nterms] words
+        std::vector<u64> apow((size_t)3 * nch * nterms);
+        for (u32 i = 0; i < nch; i++) {
+            u64 x = 1;
+            for (u32 k = 0; k < nterms; k++) {
+                const size_t e = (size_t)i * nterms + k;
+                apow[e] = x;
+                apow[(size_t)nch * nterms + 2 * e] = (x & 0x3FFFFFull) | (((x >> 22) & 0x3FFFFFull) << 32);
+                apow[(size_t)nch * nterms + 2 * e + 1] = x >> 44;
+                x = mul(x, alphas[i]);
+            }
+        }
         u64 *dev_apow, *qv, *qV, *qc;
         GLP_TRY(tmp.get(&dev_apow, apow.size()));
         GLP_TRY(h2d(c, dev_apow, apow.data(), apow.size() * 8));
@@ -1292,7 +1319,7 @@ struct glp_session {
         memset(&qp, 0, sizeof(qp));
         memset(&qbt, 0, sizeof(qbt));                    // pp == nullptr: one proof, described by qp
         a.cs = cc->cs->lde; qp.wl = wb.b->lde; qp.zl = zb.b->lde; qp.out = qv;
-        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; qp.apow = dev_apow; a.k_ratio = cc->k_ratio;
+        a.gates = cc->dev_gates; a.k_is = cc->dev_k_is; qp.apow = dev_apow; qp.apl = dev_apow + (size_t)nch * nterms; a.k_ratio = cc->k_ratio;
         for (u32 i = 0; i < nch; i++) { qp.betas[i] = betas[i]; qp.gammas[i] = gammas[i]; }
         memcpy(qp.pih, pih, 32);
         const u64 WN = root_of_unity(lg + rb), gn = pow(GEN, (u64)n), wR = root_of_unity(rb);

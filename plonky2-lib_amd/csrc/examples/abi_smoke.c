@@ -7,7 +7,16 @@
 #include <stdlib.h>
 #include "glp.h"
 
-int main(void) {
+/* argv[1] (optional): a circuit hand-off file (glp_circuit_file_*, host-only code: this part runs without a GPU).  With a GPU the
+ * circuit and witness of the file are proved through glp_circuit_create / glp_prove / glp_verify. */
+int main(int argc, char **argv) {
+    glp_circuit_file *cf = NULL;
+    if (argc > 1) {
+        if (glp_circuit_file_open(argv[1], 1, &cf) != GLP_OK) { fprintf(stderr, "glp_circuit_file_open: %s\n", glp_last_error()); return 1; }
+        const glp_circuit_desc *d = glp_circuit_file_desc(cf);
+        printf("circuit file ok: 2^%u rows, %u wires, %u gates, witness %s\n", d->degree_bits, d->num_wires, d->num_gates,
+               glp_circuit_file_wires(cf) ? "present" : "absent");
+    }
     glp_ctx *ctx = NULL;
     if (glp_ctx_create(0, &ctx) != GLP_OK) {
         fprintf(stderr, "glp_ctx_create: %s\n", glp_last_error());
@@ -32,6 +41,18 @@ int main(void) {
            (unsigned long long)cap[3]);
     glp_batch_free(b);
     free(vals);
+    if (cf && glp_circuit_file_wires(cf)) {
+        glp_circuit *circuit = NULL;
+        if (glp_circuit_create(ctx, glp_circuit_file_desc(cf), &circuit) != GLP_OK) { fprintf(stderr, "%s\n", glp_last_error()); return 1; }
+        const size_t words = glp_proof_words(circuit);
+        uint64_t *proof = (uint64_t *)malloc(sizeof(uint64_t) * words);
+        if (glp_prove(ctx, circuit, glp_circuit_file_wires(cf), glp_circuit_file_public_inputs(cf), proof) != GLP_OK ||
+            glp_verify_n(circuit, proof, words) != GLP_OK) { fprintf(stderr, "%s\n", glp_last_error()); return 1; }
+        printf("proved and verified the circuit of %s (%zu proof words)\n", argv[1], words);
+        free(proof);
+        glp_circuit_free(circuit);
+    }
+    glp_circuit_file_close(cf);
     glp_ctx_destroy(ctx);
     printf("abi_smoke ok (%s)\n", glp_version());
     return 0;

@@ -63,13 +63,15 @@ def test_header_is_plain_c_and_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(here, "include"),
                            os.path.join(pkg, "csrc", "examples", "abi_smoke.c"), "-L", pkg, "-lglprover",
                            "-Wl,-rpath," + pkg, "-o", exe])
-    r = subprocess.run([exe], capture_output=True, text=True)
+    sample = os.path.join(here, "tests", "golden", "zkdsa_2_3.glpc")
+    r = subprocess.run([exe, sample], capture_output=True, text=True)
+    assert "circuit file ok: 2^3 rows, 135 wires" in r.stdout          # the hand-off file reader is host-only code
     try:
         import torch
         has_gpu = torch.cuda.is_available()
     except Exception:
         has_gpu = False
     if has_gpu:
-        assert r.returncode == 0 and "abi_smoke ok" in r.stdout, r.stderr
+        assert r.returncode == 0 and "abi_smoke ok" in r.stdout and "proved and verified" in r.stdout, r.stderr
     else:
         assert r.returncode == 2 and "glp_ctx_create" in r.stderr

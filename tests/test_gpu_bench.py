@@ -42,3 +42,15 @@ def test_single_rank_line_has_roofline_verified_and_variants():
 def test_zkdsa_batch_workload_line():
     d = _run(["--workload", "zkdsa-batch", "--batch", "64", "--sub-batch", "32", "--threads", "2", "--steps", "1", "--warmup", "1"])
     assert d["verified"] is True and d["value"] > 0 and "glp_prove_batch" in d["config"]["workload"]
+
+
+def test_c99_consumer_proves_the_sample_circuit_file(tmp_path):
+    """A plain C program against include/glp.h (csrc/examples/abi_smoke.c): reads tests/golden/zkdsa_2_3.glpc, creates the circuit,
+    proves the file's witness and verifies the proof -- the path a Rust / Go host takes, without Python in between."""
+    pkg = os.path.join(ROOT, "plonky2-lib_amd")
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(pkg, "csrc", "examples", "abi_smoke.c"), "-L", pkg, "-lglprover", "-Wl,-rpath," + pkg, "-o", exe])
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zkdsa_2_3.glpc")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "circuit file ok: 2^3 rows, 135 wires" in r.stdout and "proved and verified" in r.stdout and "abi_smoke ok" in r.stdout

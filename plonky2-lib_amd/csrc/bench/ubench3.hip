@@ -96,6 +96,49 @@ __device__ __forceinline__ u64 mul_v6(u64 a, u64 b) {
     asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(h), "+s"(cc) : "v"(uhi));
     return fold96_asm(((u64)ulo << 32) | (u32)t, h);
 }
+// V7: the middle sum a1 b0 + a0 b1 + hi(a0 b0) as one chain whose 65th bit is the second multiply-add's carry-out; the top
+// product takes {m2.hi, carry} as its addend (one move + one select instead of three moves + a 64-bit add)
+__device__ __forceinline__ u64 mul_v7(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 e = (u64)a0 * b0;
+    const u64 m = (u64)a0 * b1 + (e >> 32);
+    u64 m2, cc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(cc) : "v"(a1), "v"(b0), "v"(m));
+    u32 chi;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(chi) : "s"(cc));
+    const u64 hi = (u64)a1 * b1 + (((u64)chi << 32) | (m2 >> 32));
+    const u64 lo = ((u64)(u32)m2 << 32) | (u32)e;
+    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t, c2;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c2) : "v"(h0), "v"(lo));
+    const u64 u = (u64)h1 * 0xFFFFFFFFu + (t >> 32);
+    u32 h; const u32 ulo = (u32)u, uhi = (u32)(u >> 32);
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(h), "+s"(c2) : "v"(uhi));
+    return fold96_asm(((u64)ulo << 32) | (u32)t, h);
+}
+// V8: V7 with the carry of the middle chain folded AFTER the top product instead of inside its addend:
+// 2^96 * carry = -carry (mod p): subtract it from the low word of y (no select, no pair building for it)
+__device__ __forceinline__ u64 mul_v8(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 e = (u64)a0 * b0;
+    const u64 m = (u64)a0 * b1 + (e >> 32);
+    u64 m2, cc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(cc) : "v"(a1), "v"(b0), "v"(m));
+    const u64 hi = (u64)a1 * b1 + (m2 >> 32);           // without the carry (worth 2^96 = -1)
+    const u64 lo = ((u64)(u32)m2 << 32) | (u32)e;
+    const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
+    u64 t, c2;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(t), "=s"(c2) : "v"(h0), "v"(lo));
+    const u64 u = (u64)h1 * 0xFFFFFFFFu + (t >> 32);
+    u32 h; const u32 ulo = (u32)u, uhi = (u32)(u >> 32);
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %1" : "=v"(h), "+s"(c2) : "v"(uhi));
+    u64 r = fold96_asm(((u64)ulo << 32) | (u32)t, h);
+    // r -= carry (mod p): r = r - c; on borrow add p back (r - c + 2^64 - EPS ... handled as: if r < c then r + p - c)
+    u32 cb;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(cb) : "s"(cc));
+    const u64 r2 = r - cb;
+    return r2 > r ? r2 - EPS : r2;          // wrapped: subtract 2^64 mod p
+}
 #define MULK(NAME, F)                                                                 \
     __global__ void NAME(u64 *out, u64 a, u64 b) {                                    \
         u64 acc[4];                                                                   \
@@ -113,6 +156,8 @@ MULK(k_mul_v3, mul_v3)
 MULK(k_sqr_v2, sqr_v2)
 MULK(k_mul_v5, mul_v5)
 MULK(k_mul_v6, mul_v6)
+MULK(k_mul_v7, mul_v7)
+MULK(k_mul_v8, mul_v8)
 
 // MDS row variants: 12 rows of 24 multiply-adds + fold
 template <int V> __device__ __forceinline__ void mds_v(u64 s[12], const u64 *rc) {
@@ -174,7 +219,7 @@ int main() {
 #define RUNM(K) { float ms = time_ms([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, out, (u64)12345, (u64)0xfedcba9876543210ull); }); \
                   u64 h4[4]; hipMemcpy(h4, out + 1000, 32, hipMemcpyDeviceToHost); \
                   printf("%-10s %7.3f ms  %7.1f lane-clk per mulmod   check %016llx\n", #K, ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 4.0 * ITERS), (unsigned long long)(h4[0] ^ h4[1] * 3 ^ h4[2] * 5 ^ h4[3] * 7)); }
-    RUNM(k_mul_v0) RUNM(k_mul_v1) RUNM(k_mul_v2) RUNM(k_mul_v3) RUNM(k_mul_v5) RUNM(k_mul_v6)
+    RUNM(k_mul_v0) RUNM(k_mul_v1) RUNM(k_mul_v2) RUNM(k_mul_v3) RUNM(k_mul_v5) RUNM(k_mul_v6) RUNM(k_mul_v7) RUNM(k_mul_v8)
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<0>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });
       printf("k_mds<0>   %7.3f ms  %7.1f lane-clk per MDS layer\n", ms, ms * 1e-3 * 2.4e9 * cus * 128 / (lanes * 256.0)); }
     { float ms = time_ms([&] { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_mds<1>), dim3(blocks), dim3(threads), 0, 0, out, (u64)5, rc); });

@@ -174,9 +174,8 @@ __device__ __forceinline__ u64 fold96_nc(u64 l, u32 h) {
 // which costs 3 half-rate VALU slots + 1 move against the 6 carry-chain slots of a 128-bit shift/sub/add
 // (profiles/r01_ubench_variants.txt: 35.9 -> 32.5 lane-clk).  The carry c travels in an SGPR pair; the s_nop
 // covers the VALU-writes-SGPR -> VALU-reads-SGPR hazard the compiler cannot see across asm blocks.
-__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
-    const unsigned __int128 p = (unsigned __int128)a * b;
-    const u64 lo = (u64)p, hi = (u64)(p >> 64);
+// lo + 2^64 hi (any 128-bit value) -> non-canonical u64, via the 97-bit y of the comment above
+__device__ __forceinline__ u64 fold128_mad_nc(u64 lo, u64 hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const u32 h0 = (u32)hi, h1 = (u32)(hi >> 32);
     u64 t, cc;
@@ -188,6 +187,31 @@ __device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
 #else
     const unsigned __int128 y = (unsigned __int128)lo + ((unsigned __int128)hi << 32) - hi;
     return fold96_nc((u64)y, (u32)(y >> 64));
+#endif
+}
+__device__ __forceinline__ u64 mul_nc(u64 a, u64 b) {
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    return fold128_mad_nc((u64)p, (u64)(p >> 64));
+}
+// The same product with the middle sum a1 b0 + a0 b1 + hi(a0 b0) as ONE multiply-add chain: its 65th bit is the second
+// multiply-add's carry-out and enters the top product's addend as {m2.hi, carry}.  From C the compiler cuts that sum into 32-bit
+// pieces and rebuilds even-aligned register pairs with moves (7 v_mov_b32 + 2 v_lshl_add_u64 per product against 5 + 1 here;
+// profiles/r02_rejected_experiments.txt): 4.40 -> 4.11 ms in the multiplier microbenchmark, 27.4 k -> 26.5 k lane-clk per Poseidon
+// permutation.  Used by the S-boxes; the NTT kernels keep mul_nc (the extra asm blocks cost k_lde_contig16 55 VGPRs and two
+// waves of occupancy).
+__device__ __forceinline__ u64 mul_nc_cc(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 e = (u64)a0 * b0;
+    const u64 mm = (u64)a0 * b1 + (e >> 32);                // < 2^64: (2^32 - 1)^2 + 2^32 - 1
+    u64 m2, mc;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(m2), "=s"(mc) : "v"(a1), "v"(b0), "v"(mm));
+    u32 chi;
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(chi) : "s"(mc));
+    const u64 hi = (u64)a1 * b1 + (((u64)chi << 32) | (m2 >> 32));     // < 2^64: the whole product is < 2^128
+    return fold128_mad_nc(((u64)(u32)m2 << 32) | (u32)e, hi);
+#else
+    return mul_nc(a, b);
 #endif
 }
 // a canonical (< p), b ANY u64 -> a + b as a non-canonical u64.  A wrapped sum is < p - 1, so adding 2^64 mod p back

@@ -85,8 +85,13 @@ GLF_HD void permute_ref(u64 s[12]) {
 static __device__ const u64 RC_ZERO[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 __device__ __forceinline__ u64 sbox7_nc(u64 x) {
+#ifdef GLP_SBOX_PLAIN_MUL
     const u64 x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
     return mul_nc(x3, x4);
+#else
+    const u64 x2 = mul_nc_cc(x, x), x4 = mul_nc_cc(x2, x2), x3 = mul_nc_cc(x, x2);
+    return mul_nc_cc(x3, x4);
+#endif
 }
 // 12 S-boxes in groups of SBOX_GROUP: the scheduling barrier keeps hipcc from interleaving all 12 chains (which
 // costs ~50 VGPRs and a wave of occupancy); within a group the chains still overlap

@@ -77,12 +77,14 @@ def pmc_traffic(stage_key, log_n):
 
 def valu_roofline(stage_key, ms, log_n, ncols):
     """Integer-issue roofline of the Poseidon leaf kernel: issue slots per permutation come from the
-    emitted ISA (profiles/isa_slots.py -> profiles/r01_poseidon_isa_slots.json; half-rate instructions
+    emitted ISA (profiles/isa_slots.py -> the newest profiles/rNN_poseidon_isa_slots.json; half-rate instructions
     count 2), peak = 256 CUs x 128 lanes/clk x 2.4 GHz (nominal clock; the chip sustains less under
     this load, see profiles/r01_ubench_int_issue*.txt)."""
-    path = os.path.join(ROOT, "profiles", "r01_poseidon_isa_slots.json")
-    if not stage_key.endswith("merkle_leaves") or not os.path.exists(path):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_poseidon_isa_slots.json")))
+    if not stage_key.endswith("merkle_leaves") or not files:
         return None
+    path = files[-1]
     slots = json.load(open(path))["slots_per_permutation"]
     perms = (1 << (log_n + 3)) * ((ncols + 7) // 8)
     ach = perms * slots / (ms / 1e3)

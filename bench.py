@@ -224,20 +224,20 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
         circuit = glp.Circuit(ctx, descs[0]) if sub else None     # one circuit, many witnesses
         wires = np.stack([d.wires for d in sub]) if sub else None
         pis = np.stack([d.public_inputs for d in sub]) if sub else None
-        workers.append([ctx, circuit, sub, wires, pis, None])
+        out = np.empty((len(sub), circuit.proof_words), np.uint64) if sub else None      # proofs land here every step
+        workers.append([ctx, circuit, sub, wires, pis, out])
 
     def step():
         def run(w):
-            ctx, circuit, sub, wires, pis, _ = w
+            ctx, circuit, sub, wires, pis, out = w
             if not sub:
                 return
             if a.per_proof:
-                w[5] = np.stack([circuit.prove(wires=d.wires, public_inputs=d.public_inputs) for d in sub])
+                for i, d in enumerate(sub):
+                    out[i] = circuit.prove(wires=d.wires, public_inputs=d.public_inputs)
             else:
-                out = []
                 for i0 in range(0, len(sub), a.sub_batch):
-                    out.append(circuit.prove_batch(wires[i0:i0 + a.sub_batch], pis[i0:i0 + a.sub_batch]))
-                w[5] = np.concatenate(out)
+                    circuit.prove_batch(wires[i0:i0 + a.sub_batch], pis[i0:i0 + a.sub_batch], out=out[i0:i0 + a.sub_batch])
         th = [threading.Thread(target=run, args=(w,)) for w in workers]
         for t in th:
             t.start()

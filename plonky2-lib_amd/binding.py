@@ -547,8 +547,9 @@ class Circuit:
         _chk(load_library().glp_proof_from_bytes(self._h, buf.ctypes.data_as(C.c_void_p), buf.size, _p(words)))
         return words
 
-    def prove_batch(self, wires, public_inputs=None):
-        """glp_prove_batch: wires [K][num_wires][n] (host array) -> proofs [K][proof_words]."""
+    def prove_batch(self, wires, public_inputs=None, out=None):
+        """glp_prove_batch: wires [K][num_wires][n] (host array) -> proofs [K][proof_words] (into `out` if given: the library
+        writes every word, so a caller that proves batch after batch can reuse one buffer)."""
         w = _a(wires)
         if w.ndim != 3 or w[0].size != self._wire_elems:
             raise GlpError(-1, "wires must be [K][num_wires][2^degree_bits]")
@@ -556,7 +557,10 @@ class Circuit:
         pi = _a(np.zeros((K, 0), np.uint64) if public_inputs is None else public_inputs).reshape(K, -1)
         if pi.shape[1] != self._num_pis:
             raise GlpError(-1, "%d public inputs per proof, the circuit has %d" % (pi.shape[1], self._num_pis))
-        out = np.zeros((K, self.proof_words), np.uint64)
+        if out is None:
+            out = np.empty((K, self.proof_words), np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (K, self.proof_words) or not out.flags.c_contiguous:
+            raise GlpError(-1, "out must be a C-contiguous uint64 array [K][proof_words]")
         _chk(load_library().glp_prove_batch(self.ctx._h, self._h, K, _p(w), 0, _p(pi) if pi.size else None, _p(out)))
         return out
 
@@ -564,7 +568,7 @@ class Circuit:
         pi = _a(np.zeros((K, 0), np.uint64) if public_inputs is None else public_inputs).reshape(K, -1)
         if pi.shape[1] != self._num_pis:
             raise GlpError(-1, "%d public inputs per proof, the circuit has %d" % (pi.shape[1], self._num_pis))
-        out = np.zeros((K, self.proof_words), np.uint64)
+        out = np.empty((K, self.proof_words), np.uint64)
         _chk(load_library().glp_prove_batch(self.ctx._h, self._h, K, C.c_void_p(dev_wires_ptr), 1, _p(pi) if pi.size else None, _p(out)))
         return out
 

@@ -889,13 +889,14 @@ __global__ __launch_bounds__(256) void k_quotient_combine(QCArgs a) {
 // zt[p] = z^bitrev(p)  (extension), from z^(2^b), b < lg
 // batch (zeta_b != nullptr, blockIdx.y = proof): the point comes from zeta_b[proof][2] and its squarings are made here
 struct ZTArgs { u64 *zt; ext2 zp2[24]; u32 lg; const u64 *zeta_b; size_t zeta_stride; };
+template <bool BATCH>
 __global__ __launch_bounds__(256) void k_zeta_table(ZTArgs a) {
     const size_t n = (size_t)1 << a.lg;
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const u32 k = bitrev32((u32)p, a.lg);
     ext2 acc = e_from(1);
-    if (a.zeta_b) {
+    if constexpr (BATCH) {
         const u64 *z = a.zeta_b + (size_t)blockIdx.y * a.zeta_stride;
         ext2 sq = e_make(z[0], z[1]);
         for (u32 b = 0; b < a.lg; b++) { if ((k >> b) & 1) acc = e_mul(acc, sq); sq = e_sqr(sq); }
@@ -1192,7 +1193,7 @@ int zeta_table(glp_ctx *c, ext2 z, int lg, u64 *dev_zt) {
     za.zt = dev_zt; za.lg = (u32)lg; za.zeta_b = nullptr; za.zeta_stride = 0;
     ext2 p = z;
     for (int b = 0; b < 24; b++) { za.zp2[b] = p; p = e_sqr(p); }
-    hipLaunchKernelGGL(k_zeta_table, dim3(nblk((size_t)1 << lg)), dim3(256), 0, c->stream, za);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_zeta_table<false>), dim3(nblk((size_t)1 << lg)), dim3(256), 0, c->stream, za);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }

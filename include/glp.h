@@ -99,6 +99,20 @@ GLP_API int glp_batch_from_coeffs(glp_ctx *ctx, const uint64_t *coeffs, uint32_t
                           uint32_t rate_bits, uint32_t cap_height, glp_batch **out);
 GLP_API int glp_batch_from_coeffs_device(glp_ctx *ctx, const uint64_t *dev_coeffs, uint32_t ncols, uint32_t log_n,
                                  uint32_t rate_bits, uint32_t cap_height, glp_batch **out);
+/* The hash of the commitment: plonky2's `GenericConfig::Hasher`.  GLP_HASH_POSEIDON = PoseidonGoldilocksConfig (every driver of the
+ * reference but one); GLP_HASH_KECCAK25 = KeccakGoldilocksConfig, `KeccakHash<25>` [REF src/hash/keccak256.rs:281]: Keccak-256
+ * truncated to 25 bytes; such a digest occupies the same 4-word slot as a Poseidon HashOut (little-endian bytes, top 7 bytes of the
+ * last word zero), so caps, paths and digest arrays keep their shapes.  The *_h entry points are the ones above with the hash named. */
+#define GLP_HASH_POSEIDON 0
+#define GLP_HASH_KECCAK25 1
+GLP_API int glp_batch_from_values_h(glp_ctx *ctx, const uint64_t *values, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                    uint32_t cap_height, uint32_t hasher, glp_batch **out);
+GLP_API int glp_batch_from_coeffs_h(glp_ctx *ctx, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
+                                    uint32_t cap_height, uint32_t hasher, glp_batch **out);
+/* Keccak-256 of `count` messages of `len` bytes each (msgs [count][len], digests_out [count][32]) on the GPU: the primitive under
+ * GLP_HASH_KECCAK25, exposed so that it can be checked against the reference's (input, digest) pairs
+ * [REF src/hash/keccak256.rs:196-212,256-277]. */
+GLP_API int glp_keccak256(glp_ctx *ctx, const uint8_t *msgs, size_t count, size_t len, uint8_t *digests_out);
 GLP_API void glp_batch_free(glp_batch *b);
 GLP_API int glp_batch_info(const glp_batch *b, uint32_t *ncols, uint32_t *log_n, uint32_t *rate_bits, uint32_t *cap_height);
 /* merkle_tree.cap: [2^cap_height][4] */

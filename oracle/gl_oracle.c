@@ -21,6 +21,7 @@
  * naive 30-round Poseidon, row-major leaves) and shares no code with the HIP library.
  */
 #include "gl_field.h"
+#include "gl_keccak.h"
 #include "poseidon_constants.h"
 #include <stdlib.h>
 #include <string.h>
@@ -105,12 +106,28 @@ API void glo_hash_no_pad(const u64 *in, size_t len, u64 out[4]) {
     memcpy(out, st, 4 * sizeof(u64));
 }
 /* Hasher::hash_or_noop: <=4 elements are copied (zero padded), not hashed. */
+/* ---- GenericConfig::Hasher: 0 = PoseidonHash (PoseidonGoldilocksConfig), 1 = KeccakHash<25> (KeccakGoldilocksConfig, the one
+ * driver [REF src/hash/keccak256.rs:281]; conventions in gl_keccak.h).  A process-wide switch: this is test infrastructure, the
+ * Python side sets it around each call (oracle.py).  The public-input hash is the INNER hasher, Poseidon in both configs. */
+static int g_hasher = 0;
+API void glo_set_hasher(int h) { g_hasher = h; }
+API int glo_get_hasher(void) { return g_hasher; }
 API void glo_hash_or_noop(const u64 *in, size_t len, u64 out[4]) {
+    if (g_hasher == 1) { glo_keccak_hash_or_noop(in, len, out); return; }
     if (len <= 4) { for (int i = 0; i < 4; i++) out[i] = (size_t)i < len ? in[i] : 0; }
     else glo_hash_no_pad(in, len, out);
 }
+/* C::Hasher::hash_no_pad (circuit digest) */
+API void glo_outer_hash_no_pad(const u64 *in, size_t len, u64 out[4]) {
+    if (g_hasher == 1) glo_keccak_hash_no_pad(in, len, out); else glo_hash_no_pad(in, len, out);
+}
+/* the sponge permutation of the transcript: H::Permutation */
+API void glo_permute(u64 st[12]) {
+    if (g_hasher == 1) glo_keccak_permute(st); else glo_poseidon_permute(st);
+}
 /* hashing.rs `compress`: perm(left || right || 0000)[0..4] */
 API void glo_two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
+    if (g_hasher == 1) { glo_keccak_two_to_one(l, r, out); return; }
     u64 st[12] = {0};
     memcpy(st, l, 32); memcpy(st + 4, r, 32);
     glo_poseidon_permute(st);
@@ -276,7 +293,7 @@ API void glo_challenger_init(glo_challenger *c) { memset(c, 0, sizeof(*c)); }
 static void ch_duplex(glo_challenger *c) {
     for (int i = 0; i < c->nin; i++) c->st[i] = c->in[i];
     c->nin = 0;
-    glo_poseidon_permute(c->st);
+    glo_permute(c->st);
     memcpy(c->out, c->st, 64); c->nout = 8;
 }
 API void glo_challenger_observe(glo_challenger *c, const u64 *e, size_t n) {
@@ -284,6 +301,13 @@ API void glo_challenger_observe(glo_challenger *c, const u64 *e, size_t n) {
         c->nout = 0;
         c->in[c->nin++] = e[i];
         if (c->nin == 8) ch_duplex(c);
+    }
+}
+/* observe_hash / observe_cap for hashes of the OUTER hasher: a Poseidon HashOut is its 4 elements, a BytesHash<25> its 7-byte chunks */
+API void glo_challenger_observe_hashes(glo_challenger *c, const u64 *digests, size_t count) {
+    for (size_t i = 0; i < count; i++) {
+        if (g_hasher == 1) { u64 e[4]; glo_keccak_hash_to_elements(digests + 4 * i, e); glo_challenger_observe(c, e, 4); }
+        else glo_challenger_observe(c, digests + 4 * i, 4);
     }
 }
 API u64 glo_challenger_get(glo_challenger *c) {

@@ -50,6 +50,8 @@ int glo_batch_from_coeffs(const u64 *coeffs, size_t ncols, int lg, int rate_bits
 typedef struct { u64 st[12]; u64 in[8]; int nin; u64 out[8]; int nout; } glo_challenger;
 void glo_challenger_init(glo_challenger *c);
 void glo_challenger_observe(glo_challenger *c, const u64 *e, size_t n);
+void glo_challenger_observe_hashes(glo_challenger *c, const u64 *digests, size_t count);   /* outer-hasher digests (caps, circuit digest) */
+void glo_permute(u64 st[12]);                                                            /* the transcript's permutation */
 u64 glo_challenger_get(glo_challenger *c);
 
 static size_t brev(size_t x, int bits) {
@@ -462,9 +464,9 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
     memcpy(proof + L.caps, wb.cap, capn * 32);
 
     glo_challenger ch; glo_challenger_init(&ch);
-    glo_challenger_observe(&ch, c->circuit_digest, 4);
+    glo_challenger_observe_hashes(&ch, c->circuit_digest, 1);
     glo_challenger_observe(&ch, pih, 4);
-    glo_challenger_observe(&ch, wb.cap, capn * 4);
+    glo_challenger_observe_hashes(&ch, wb.cap, capn);
     u64 betas[8], gammas[8], alphas[8];
     for (u32 i = 0; i < nch; i++) betas[i] = glo_challenger_get(&ch);
     for (u32 i = 0; i < nch; i++) gammas[i] = glo_challenger_get(&ch);
@@ -507,7 +509,7 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
     obatch zb; obatch_from_values(&zb, zp, nzp, c);
     free(zp);
     memcpy(proof + L.caps + capn * 4, zb.cap, capn * 32);
-    glo_challenger_observe(&ch, zb.cap, capn * 4);
+    glo_challenger_observe_hashes(&ch, zb.cap, capn);
     for (u32 i = 0; i < nch; i++) alphas[i] = glo_challenger_get(&ch);
 
     /* compute_quotient_polys: evaluate on the coset 7*<w_{n*qdf}> (qdf = 2^quotient_degree_bits <= 2^rate_bits) */
@@ -559,7 +561,7 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
      * degree < qdf*n on the coset, detected below by the opening check in tests. */
     obatch qb; obatch_from_coeffs(&qb, qc, (size_t)nch * qdf, c);
     memcpy(proof + L.caps + 2 * capn * 4, qb.cap, capn * 32);
-    glo_challenger_observe(&ch, qb.cap, capn * 4);
+    glo_challenger_observe_hashes(&ch, qb.cap, capn);
 
     gl2 zeta = ch_get_ext(&ch);
     gl2 g = gl2_from(gl_root_of_unity(lg));
@@ -656,7 +658,7 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
         u64 cap[64 * 4];
         glo_merkle_build(leaves, nl, 2 * arity, c->cap_height, dig, cap);
         memcpy(proof + L.fri_caps + (size_t)r * capn * 4, cap, capn * 32);
-        glo_challenger_observe(&ch, cap, capn * 4);
+        glo_challenger_observe_hashes(&ch, cap, capn);
         tree_dig[r] = dig; tree_leaves[r] = leaves;
         gl2 beta = ch_get_ext(&ch);
         /* coeffs <- chunks(arity).map(reduce_with_powers(chunk, beta)) */
@@ -683,7 +685,7 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
         for (;; cand++) {
             u64 t[12]; memcpy(t, st, 96);
             t[pos] = cand;
-            glo_poseidon_permute(t);
+            glo_permute(t);
             if (c->proof_of_work_bits == 0 || (t[7] >> (64 - c->proof_of_work_bits)) == 0) break;
         }
         proof[L.pow] = cand;
@@ -733,15 +735,15 @@ API int glo_verify(const glo_circuit *c, const u64 *constants_sigmas_cap, const 
     u64 pih[4];
     glo_hash_no_pad(proof + L.pis, c->num_public_inputs, pih);
     glo_challenger ch; glo_challenger_init(&ch);
-    glo_challenger_observe(&ch, c->circuit_digest, 4);
+    glo_challenger_observe_hashes(&ch, c->circuit_digest, 1);
     glo_challenger_observe(&ch, pih, 4);
-    glo_challenger_observe(&ch, proof + L.caps, capn * 4);
+    glo_challenger_observe_hashes(&ch, proof + L.caps, capn);
     u64 betas[8], gammas[8], alphas[8];
     for (u32 i = 0; i < nch; i++) betas[i] = glo_challenger_get(&ch);
     for (u32 i = 0; i < nch; i++) gammas[i] = glo_challenger_get(&ch);
-    glo_challenger_observe(&ch, proof + L.caps + capn * 4, capn * 4);
+    glo_challenger_observe_hashes(&ch, proof + L.caps + capn * 4, capn);
     for (u32 i = 0; i < nch; i++) alphas[i] = glo_challenger_get(&ch);
-    glo_challenger_observe(&ch, proof + L.caps + 2 * capn * 4, capn * 4);
+    glo_challenger_observe_hashes(&ch, proof + L.caps + 2 * capn * 4, capn);
     gl2 zeta = ch_get_ext(&ch);
 
     const u64 *op = proof + L.openings;
@@ -757,7 +759,7 @@ API int glo_verify(const glo_circuit *c, const u64 *constants_sigmas_cap, const 
     gl2 fri_alpha = ch_get_ext(&ch);
     gl2 fri_betas[16];
     for (u32 r = 0; r < c->num_reductions; r++) {
-        glo_challenger_observe(&ch, proof + L.fri_caps + (size_t)r * capn * 4, capn * 4);
+        glo_challenger_observe_hashes(&ch, proof + L.fri_caps + (size_t)r * capn * 4, capn);
         fri_betas[r] = ch_get_ext(&ch);
     }
     glo_challenger_observe(&ch, proof + L.final_poly, 2 * (size_t)L.final_len);

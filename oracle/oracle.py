@@ -42,6 +42,7 @@ def lib():
         L.glo_merkle_num_digests.argtypes = [C.c_size_t, C.c_int]
         L.glo_challenger_size.restype = C.c_size_t
         L.glo_challenger_get.restype = C.c_uint64
+        L.glo_get_hasher.restype = C.c_int
     return _lib
 
 
@@ -123,6 +124,38 @@ def two_to_one(l, r):
     lib().glo_two_to_one(_p(l), _p(r), _p(o)); return o
 
 
+# ---------------------------------------------------------------- Keccak (gl_keccak.c; KeccakGoldilocksConfig)
+def keccak256(msg: bytes) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().glo_keccak256(C.c_char_p(bytes(msg)), C.c_size_t(len(msg)), out)
+    return out.raw
+
+
+def keccak_hash_no_pad(x):
+    x = _a(x); o = np.empty(4, np.uint64)
+    lib().glo_keccak_hash_no_pad(_p(x), C.c_size_t(x.size), _p(o)); return o
+
+
+def keccak_hash_or_noop(x):
+    x = _a(x); o = np.empty(4, np.uint64)
+    lib().glo_keccak_hash_or_noop(_p(x), C.c_size_t(x.size), _p(o)); return o
+
+
+def keccak_two_to_one(l, r):
+    l, r = _a(l), _a(r); o = np.empty(4, np.uint64)
+    lib().glo_keccak_two_to_one(_p(l), _p(r), _p(o)); return o
+
+
+def keccak_hash_to_elements(h):
+    h = _a(h); o = np.empty(4, np.uint64)
+    lib().glo_keccak_hash_to_elements(_p(h), _p(o)); return o
+
+
+def keccak_permute(state):
+    s = _a(state).copy(); assert s.size == 12
+    lib().glo_keccak_permute(_p(s)); return s
+
+
 # ---------------------------------------------------------------- FFT
 def fft(a):
     a = _a(a).copy(); lib().glo_fft(_p(a), C.c_int(int(a.size).bit_length() - 1)); return a
@@ -159,6 +192,14 @@ def merkle_num_digests(nleaves, cap_height):
     return lib().glo_merkle_num_digests(nleaves, cap_height)
 
 
+class _Hasher:
+    """`with _Hasher(h):` selects GenericConfig::Hasher for the oracle calls inside (0 = Poseidon, 1 = KeccakHash<25>); the C
+    side keeps it in one process-wide variable (test infrastructure)."""
+    def __init__(self, h): self.h = int(h)
+    def __enter__(self): self.prev = lib().glo_get_hasher(); lib().glo_set_hasher(self.h)
+    def __exit__(self, *a): lib().glo_set_hasher(self.prev)
+
+
 def merkle_build(leaves, cap_height):
     """leaves [nleaves][leaf_len] -> (digests [num][4] level-major bottom-up, cap [2^cap_height][4])."""
     leaves = _a(leaves); nl, ll = leaves.shape
@@ -175,11 +216,12 @@ def merkle_prove(digests, nleaves, cap_height, index):
     return sib[:k].copy()
 
 
-def merkle_verify(leaf, index, cap, siblings):
+def merkle_verify(leaf, index, cap, siblings, hasher=0):
     leaf, cap, siblings = _a(leaf), _a(cap), _a(siblings).reshape(-1, 4)
     ch = int(cap.shape[0]).bit_length() - 1
-    return lib().glo_merkle_verify(_p(leaf), C.c_size_t(leaf.size), C.c_size_t(index), _p(cap), C.c_int(ch),
-                                   _p(siblings), C.c_int(siblings.shape[0])) == 0
+    with _Hasher(hasher):
+        return lib().glo_merkle_verify(_p(leaf), C.c_size_t(leaf.size), C.c_size_t(index), _p(cap), C.c_int(ch),
+                                       _p(siblings), C.c_int(siblings.shape[0])) == 0
 
 
 class Batch:
@@ -192,7 +234,17 @@ class Batch:
         return merkle_prove(self.digests, self.leaves.shape[0], self.cap_height, index)
 
 
-def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4):
+def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4, hasher=0):
+    with _Hasher(hasher):
+        return _batch_from_coeffs(coeffs, rate_bits, cap_height)
+
+
+def batch_from_values(values, rate_bits=3, cap_height=4, hasher=0):
+    with _Hasher(hasher):
+        return _batch_from_values(values, rate_bits, cap_height)
+
+
+def _batch_from_coeffs(coeffs, rate_bits=3, cap_height=4):
     coeffs = _a(coeffs); ncols, n = coeffs.shape; lg = n.bit_length() - 1
     N = n << rate_bits
     leaves = np.empty((N, ncols), np.uint64)
@@ -204,7 +256,7 @@ def batch_from_coeffs(coeffs, rate_bits=3, cap_height=4):
     return Batch(coeffs, leaves, dig, cap, rate_bits, cap_height)
 
 
-def batch_from_values(values, rate_bits=3, cap_height=4):
+def _batch_from_values(values, rate_bits=3, cap_height=4):
     values = _a(values); ncols, n = values.shape; lg = n.bit_length() - 1
     N = n << rate_bits
     coeffs = np.empty_like(values)
@@ -265,6 +317,7 @@ class OracleCircuit:
     def __init__(self, c, cs_cap=None):
         """cs_cap: optional constants+sigmas Merkle cap (verifier_only data); if omitted it is computed here."""
         self.c = c
+        self.hasher = int(getattr(c, "hasher", 0))
         self._k = _a(c.k_is); self._const = _a(c.constants); self._sig = _a(c.sigmas)
         self._gates = (_Gate * len(c.gates))()
         for i, g in enumerate(c.gates):
@@ -287,11 +340,12 @@ class OracleCircuit:
         L.glo_proof_words.restype = C.c_size_t
         if cs_cap is None:
             self.cs_cap = np.empty((1 << c.cap_height, 4), np.uint64)
-            L.glo_constants_sigmas_cap(C.byref(s), _p(self.cs_cap))
+            with _Hasher(self.hasher):
+                L.glo_constants_sigmas_cap(C.byref(s), _p(self.cs_cap))
         else:
             self.cs_cap = _a(cs_cap).reshape(1 << c.cap_height, 4).copy()
         if getattr(c, "circuit_digest", None) is None:
-            c.circuit_digest = circuit_digest(self.cs_cap, c.degree_bits)
+            c.circuit_digest = circuit_digest(self.cs_cap, c.degree_bits, self.hasher)
         for i in range(4):
             s.circuit_digest[i] = int(c.circuit_digest[i])
         self.proof_words = L.glo_proof_words(C.byref(s))
@@ -300,7 +354,8 @@ class OracleCircuit:
         w = _a(self.c.wires if wires is None else wires)
         pi = _a(self.c.public_inputs if public_inputs is None else public_inputs)
         proof = np.zeros(self.proof_words, np.uint64)
-        rc = lib().glo_prove(C.byref(self.s), _p(w), _p(pi) if pi.size else None, _p(proof))
+        with _Hasher(self.hasher):
+            rc = lib().glo_prove(C.byref(self.s), _p(w), _p(pi) if pi.size else None, _p(proof))
         return rc, proof
 
     def witness_fill(self, wires, only_advice=False):
@@ -310,11 +365,18 @@ class OracleCircuit:
         return w
 
     def verify(self, proof):
-        return lib().glo_verify(C.byref(self.s), _p(self.cs_cap), _p(_a(proof)))
+        with _Hasher(self.hasher):
+            return lib().glo_verify(C.byref(self.s), _p(self.cs_cap), _p(_a(proof)))
 
 
-def circuit_digest(constants_sigmas_cap, degree_bits):
-    """plonk/circuit_builder.rs build(): hash_no_pad(cap.flatten() ++ hash_pad(domain_separator = []) ++ [degree_bits])."""
-    ds = hash_pad(np.zeros(0, np.uint64))
-    parts = np.concatenate([_a(constants_sigmas_cap).reshape(-1), ds, np.array([degree_bits], np.uint64)])
-    return hash_no_pad(parts)
+def circuit_digest(constants_sigmas_cap, degree_bits, hasher=0):
+    """plonk/circuit_builder.rs build(): C::Hasher::hash_no_pad(cap.flatten() ++ hash_pad(domain_separator = []).to_vec() ++ [degree_bits]).
+    With KeccakHash<25> a hash "flattens" to its four 7-byte chunks (BytesHash::to_vec) and hash_pad pads to the sponge width 12 as for Poseidon."""
+    if hasher == 0:
+        ds = hash_pad(np.zeros(0, np.uint64))
+        parts = np.concatenate([_a(constants_sigmas_cap).reshape(-1), ds, np.array([degree_bits], np.uint64)])
+        return hash_no_pad(parts)
+    pad = np.array([1] + [0] * 10 + [1], np.uint64)                      # hash_pad([]): 1, zeros up to width - 1, 1
+    ds = keccak_hash_to_elements(keccak_hash_no_pad(pad))
+    cap_e = np.concatenate([keccak_hash_to_elements(h) for h in _a(constants_sigmas_cap).reshape(-1, 4)])
+    return keccak_hash_no_pad(np.concatenate([cap_e, ds, np.array([degree_bits], np.uint64)]))

@@ -91,6 +91,9 @@ def load_library():
         "glp_batch_from_values_device": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
         "glp_batch_from_coeffs": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
         "glp_batch_from_coeffs_device": [vp, vp, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_batch_from_values_h": [vp, vp, u32, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_batch_from_coeffs_h": [vp, vp, u32, u32, u32, u32, u32, C.POINTER(vp)],
+        "glp_keccak256": [vp, vp, sz, sz, vp],
         "glp_batch_free": [vp],
         "glp_batch_info": [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)],
         "glp_batch_cap": [vp, vp],
@@ -273,11 +276,24 @@ class Context:
         _chk(load_library().glp_fill_random_device(self._h, C.c_void_p(dev_ptr), count, seed))
 
     # -- PolynomialBatch
-    def batch_from_values(self, values, rate_bits=3, cap_height=4):
-        return Batch._make(self, "glp_batch_from_values", values, rate_bits, cap_height)
+    def batch_from_values(self, values, rate_bits=3, cap_height=4, hasher=0):
+        return Batch._make(self, "glp_batch_from_values_h", values, rate_bits, cap_height, hasher)
 
-    def batch_from_coeffs(self, coeffs, rate_bits=3, cap_height=4):
-        return Batch._make(self, "glp_batch_from_coeffs", coeffs, rate_bits, cap_height)
+    def batch_from_coeffs(self, coeffs, rate_bits=3, cap_height=4, hasher=0):
+        return Batch._make(self, "glp_batch_from_coeffs_h", coeffs, rate_bits, cap_height, hasher)
+
+    def keccak256(self, msgs):
+        """Keccak-256 of equal-length byte strings on the GPU (glp_keccak256): list of bytes -> list of 32-byte digests."""
+        msgs = [bytes(m) for m in msgs]
+        if not msgs:
+            return []
+        n = len(msgs[0])
+        if any(len(m) != n for m in msgs):
+            raise GlpError(-1, "glp_keccak256 takes messages of one length")
+        buf = np.frombuffer(b"".join(msgs) or b"\0", dtype=np.uint8)
+        out = np.zeros((len(msgs), 32), np.uint8)
+        _chk(load_library().glp_keccak256(self._h, buf.ctypes.data_as(C.c_void_p), len(msgs), n, out.ctypes.data_as(C.c_void_p)))
+        return [bytes(r) for r in out]
 
     def batch_from_values_device(self, dev_ptr, ncols, log_n, rate_bits=3, cap_height=4):
         return Batch._make_dev(self, "glp_batch_from_values_device", dev_ptr, ncols, log_n, rate_bits, cap_height)
@@ -294,7 +310,7 @@ class Batch:
         self.ncols, self.log_n, self.rate_bits, self.cap_height = ncols, log_n, rate_bits, cap_height
 
     @classmethod
-    def _make(cls, ctx, fn, arr, rate_bits, cap_height):
+    def _make(cls, ctx, fn, arr, rate_bits, cap_height, hasher=0):
         a = _a(arr)
         if a.ndim != 2:
             raise GlpError(-1, "expected a [ncols][n] array")
@@ -302,7 +318,7 @@ class Batch:
         if n & (n - 1) or n == 0:
             raise GlpError(-1, "n must be a power of two")
         h = C.c_void_p()
-        _chk(getattr(load_library(), fn)(ctx._h, _p(a), ncols, n.bit_length() - 1, rate_bits, cap_height, C.byref(h)))
+        _chk(getattr(load_library(), fn)(ctx._h, _p(a), ncols, n.bit_length() - 1, rate_bits, cap_height, int(hasher), C.byref(h)))
         return cls(ctx, h, ncols, n.bit_length() - 1, rate_bits, cap_height)
 
     @classmethod

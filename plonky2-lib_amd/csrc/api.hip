@@ -4,6 +4,7 @@
 #include <string.h>
 #include "batch.h"
 #include "common.h"
+#include "keccak.h"
 #include "merkle.h"
 #include "ntt.h"
 
@@ -300,6 +301,40 @@ __global__ void k_fill_random(u64 *out, size_t count, u64 seed) {
     out[i] = glf::canon(z);
 }
 
+// one message per thread, bytes packed into lanes on the fly
+__global__ void k_keccak256(const uint8_t *msgs, size_t count, size_t len, uint8_t *out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint8_t *m = msgs + i * len;
+    kec::Sponge s;
+    kec::sponge_init(s);
+    size_t off = 0;
+    for (; off + 8 <= len; off += 8) {
+        u64 lane = 0;
+        for (int b = 0; b < 8; b++) lane |= (u64)m[off + b] << (8 * b);
+        kec::sponge_absorb(s, lane);
+    }
+    u64 extra = 0;
+    for (size_t b = 0; off + b < len; b++) extra |= (u64)m[off + b] << (8 * b);
+    kec::sponge_finish(s, extra, (int)(len - off));
+    for (int w = 0; w < 4; w++) for (int b = 0; b < 8; b++) out[i * 32 + 8 * w + b] = (uint8_t)(s.a[w] >> (8 * b));
+}
+extern "C" int glp_keccak256(glp_ctx *c, const uint8_t *msgs, size_t count, size_t len, uint8_t *digests_out) {
+    GLP_REQUIRE(c && digests_out && (msgs || !len), "null argument");
+    GLP_TRY(bind(c));
+    if (!count) return GLP_OK;
+    Scratch s(c);
+    u64 *dm, *dd;
+    GLP_TRY(s.get(&dm, (count * len + 7) / 8 + 1));
+    GLP_TRY(s.get(&dd, count * 4));
+    if (len) GLP_HIP(hipMemcpyAsync(dm, msgs, count * len, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_keccak256, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, c->stream, (const uint8_t *)dm, count, len, (uint8_t *)dd);
+    GLP_HIP(hipGetLastError());
+    GLP_HIP(hipMemcpyAsync(digests_out, dd, count * 32, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    return GLP_OK;
+}
+
 extern "C" int glp_fill_random_device(glp_ctx *c, uint64_t *dev_out, size_t count, uint64_t seed) {
     GLP_REQUIRE(c && (dev_out || !count), "null argument");
     GLP_TRY(bind(c));
@@ -328,9 +363,10 @@ void batch_destroy(glp_batch *b) {
 // host_src != nullptr (BATCH_VALUES only): the values are still in host memory; they are copied into dev_in in column
 // chunks on the copy stream while the transforms of the chunks already on the device run on the compute stream.
 int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg, int rate_bits, int cap_height,
-                glp_batch **out, const u64 *host_src, u32 K) {
+                glp_batch **out, const u64 *host_src, u32 K, int hasher) {
     GLP_REQUIRE(out, "out is null");
     *out = nullptr;
+    if (hasher != GLP_HASH_POSEIDON && hasher != GLP_HASH_KECCAK25) return set_error(GLP_ERR_UNSUPPORTED, "hasher %d is not one of GLP_HASH_*", hasher);
     GLP_REQUIRE(ncols > 0, "ncols must be positive");
     GLP_REQUIRE(K >= 1 && (K == 1 || host_src == nullptr), "bad batch arguments");
     if (K > 1) {
@@ -338,7 +374,7 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
         GLP_REQUIRE(rate_bits >= 0 && rate_bits <= 4 && cap_height >= 0 && cap_height <= lg + rate_bits && lg <= NTT_MAX_LG, "bad batch shape");
         const size_t n = (size_t)1 << lg, N = n << rate_bits;
         std::unique_ptr<glp_batch, void (*)(glp_batch *)> b(new glp_batch(), batch_destroy);
-        b->ctx = c; b->ncols = ncols; b->lg = lg; b->rate_bits = rate_bits; b->cap_height = cap_height; b->K = K;
+        b->ctx = c; b->ncols = ncols; b->lg = lg; b->rate_bits = rate_bits; b->cap_height = cap_height; b->K = K; b->hasher = hasher;
         b->ndigests = merkle_num_digests(N, cap_height);
         const size_t tot = (size_t)K * ncols;
         GLP_REQUIRE(tot <= 0x7FFFFFFFu, "batch too wide");
@@ -349,7 +385,7 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
         else if (input_kind == BATCH_COEFFS_NATURAL) GLP_TRY(bitrev_copy(c, dev_in, b->coeffs, (u32)tot, lg));
         else GLP_HIP(hipMemcpyAsync(b->coeffs, dev_in, tot * n * 8, hipMemcpyDeviceToDevice, c->stream));
         GLP_TRY(lde_coeffs(c, b->coeffs, b->lde, (u32)tot, lg, rate_bits, glf::GEN));
-        GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests, K, (size_t)ncols * N, b->ndigests * 4));
+        GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests, K, (size_t)ncols * N, b->ndigests * 4, hasher));
         *out = b.release();
         return GLP_OK;
     }
@@ -359,7 +395,7 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
                 lg + rate_bits);
     const size_t n = (size_t)1 << lg, N = n << rate_bits;
     std::unique_ptr<glp_batch, void (*)(glp_batch *)> b(new glp_batch(), batch_destroy);
-    b->ctx = c; b->ncols = ncols; b->lg = lg; b->rate_bits = rate_bits; b->cap_height = cap_height;
+    b->ctx = c; b->ncols = ncols; b->lg = lg; b->rate_bits = rate_bits; b->cap_height = cap_height; b->hasher = hasher;
     b->ndigests = merkle_num_digests(N, cap_height);
     GLP_TRY(c->alloc((void **)&b->coeffs, (size_t)ncols * n * 8));
     GLP_TRY(c->alloc((void **)&b->lde, (size_t)ncols * N * 8));
@@ -391,7 +427,7 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
         if (rc != GLP_OK || !evs.empty()) (void)hipStreamSynchronize(c->copy_stream);
         for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
         GLP_TRY(rc);
-        GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests));
+        GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests, 1, 0, 0, hasher));
         *out = b.release();
         return GLP_OK;
     }
@@ -409,13 +445,13 @@ int batch_build(glp_ctx *c, const u64 *dev_in, int input_kind, u32 ncols, int lg
         StageScope st(c, "lde", (8.0 * n + 8.0 * N) * ncols);
         GLP_TRY(lde_coeffs(c, b->coeffs, b->lde, ncols, lg, rate_bits, glf::GEN));
     }
-    GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests));
+    GLP_TRY(merkle_from_lde(c, b->lde, ncols, lg, rate_bits, cap_height, b->digests, 1, 0, 0, hasher));
     *out = b.release();
     return GLP_OK;
 }
 
 static int batch_from_host(glp_ctx *c, const u64 *host, bool from_values, u32 ncols, u32 log_n, u32 rate_bits, u32 cap_height,
-                           glp_batch **out) {
+                           glp_batch **out, int hasher = GLP_HASH_POSEIDON) {
     GLP_REQUIRE(c && host && out, "null argument");
     GLP_TRY(bind(c));
     if (log_n > (u32)NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%u > %d", log_n, NTT_MAX_LG);
@@ -424,11 +460,11 @@ static int batch_from_host(glp_ctx *c, const u64 *host, bool from_values, u32 nc
     GLP_TRY(c->alloc(&d, tot * 8));
     int rc = GLP_OK;
     if (from_values) {       // upload pipelined with the transforms
-        rc = batch_build(c, (const u64 *)d, BATCH_VALUES, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out, host);
+        rc = batch_build(c, (const u64 *)d, BATCH_VALUES, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out, host, 1, hasher);
     } else {
         hipError_t e = hipMemcpyAsync(d, host, tot * 8, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "H2D copy: %s", hipGetErrorString(e));
-        if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, BATCH_COEFFS_NATURAL, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out);
+        if (rc == GLP_OK) rc = batch_build(c, (const u64 *)d, BATCH_COEFFS_NATURAL, ncols, (int)log_n, (int)rate_bits, (int)cap_height, out, nullptr, 1, hasher);
     }
     (void)hipStreamSynchronize(c->stream);
     c->release(d);
@@ -446,6 +482,14 @@ int glp_batch_from_values(glp_ctx *c, const uint64_t *values, uint32_t ncols, ui
 int glp_batch_from_coeffs(glp_ctx *c, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
                           uint32_t cap_height, glp_batch **out) {
     return batch_from_host(c, coeffs, false, ncols, log_n, rate_bits, cap_height, out);
+}
+int glp_batch_from_values_h(glp_ctx *c, const uint64_t *values, uint32_t ncols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height,
+                            uint32_t hasher, glp_batch **out) {
+    return batch_from_host(c, values, true, ncols, log_n, rate_bits, cap_height, out, (int)hasher);
+}
+int glp_batch_from_coeffs_h(glp_ctx *c, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits, uint32_t cap_height,
+                            uint32_t hasher, glp_batch **out) {
+    return batch_from_host(c, coeffs, false, ncols, log_n, rate_bits, cap_height, out, (int)hasher);
 }
 int glp_batch_from_values_device(glp_ctx *c, const uint64_t *dev_values, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
                                  uint32_t cap_height, glp_batch **out) {

@@ -11,6 +11,7 @@
 // column per wave.  No transpose pass exists; the bit-reversed leaf order of plonky2 is produced
 // by scattering the 32-byte digest to slot bitrev(pos).
 #include "merkle.h"
+#include "keccak.h"
 #include "poseidon.h"
 
 namespace glp {
@@ -160,13 +161,59 @@ __global__ void k_permute_states(u64 *states, size_t count) {
     for (int k = 0; k < 12; k++) states[12 * i + k] = s[k];
 }
 
-static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height, u32 K = 1, size_t dig_stride = 0) {
+// ---- KeccakHash<25> (KeccakGoldilocksConfig): the same tree with Keccak-256 leaves and nodes (keccak.h) ----------------------
+// hash_or_noop of one LDE row per lane: <= 3 columns are copied, otherwise the row's elements ARE the sponge's 64-bit lanes, 17 per
+// rate block.  Bitwise work only (full-rate VALU): this tree is HBM / latency bound, not issue bound like the Poseidon one.
+__global__ __launch_bounds__(256) void k_leaf_hash_lde_keccak(const u64 *__restrict__ lde, u64 *__restrict__ digests, u32 ncols, int lg,
+                                                              int rate_bits, size_t lde_stride, size_t dig_stride) {
+    lde += (size_t)blockIdx.y * lde_stride; digests += (size_t)blockIdx.y * dig_stride;
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    const size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (pos >= N) return;
+    const u32 r = (u32)(pos >> lg), q = (u32)(pos & (((size_t)1 << lg) - 1));
+    const size_t leaf = ((size_t)bitrev32(r, rate_bits) << lg) | bitrev32(q, lg);
+    const u64 *p = lde + pos;
+    u64 d[4] = {0, 0, 0, 0};
+    if (ncols <= 3) {
+        for (u32 c = 0; c < ncols; c++) d[c] = p[(size_t)c * N];
+    } else {
+        kec::Sponge s;
+        kec::sponge_init(s);
+        u32 c = 0;
+        for (; c + kec::RATE_LANES <= ncols; c += kec::RATE_LANES) {
+#pragma unroll
+            for (int i = 0; i < kec::RATE_LANES; i++) s.a[i] ^= p[(size_t)(c + i) * N];
+            kec::f1600(s.a);
+        }
+#pragma unroll
+        for (int i = 0; i < kec::RATE_LANES; i++) if (c + i < ncols) s.a[i] ^= p[(size_t)(c + i) * N];
+        s.fill = (int)(ncols - c);
+        kec::sponge_finish(s);
+        kec::sponge_digest25(s, d);
+    }
+    store_digest(digests + 4 * leaf, d);
+}
+__global__ __launch_bounds__(256) void k_merkle_level_keccak(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m, size_t dig_stride) {
+    in += (size_t)blockIdx.y * dig_stride; out += (size_t)blockIdx.y * dig_stride;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(in + 8 * i);
+    const ulonglong2 a = src[0], b = src[1], c2 = src[2], e = src[3];
+    const u64 l[4] = {a.x, a.y, b.x, b.y}, r[4] = {c2.x, c2.y, e.x, e.y};
+    u64 d[4];
+    kec::two_to_one(l, r, d);
+    store_digest(out + 4 * i, d);
+}
+
+static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height, u32 K = 1, size_t dig_stride = 0, int hasher = 0) {
     size_t w = nleaves, cap = (size_t)1 << cap_height;
     u64 *lvl = dev_digests;
     while (w > cap) {
         u64 *nxt = lvl + 4 * w;
         size_t m = w >> 1;
-        if (m * K <= MERKLE_COOP_MAX_PARENTS)   // few hashes: 12 lanes per hash for latency
+        if (hasher == GLP_HASH_KECCAK25)
+            hipLaunchKernelGGL(k_merkle_level_keccak, dim3((unsigned)((m + 255) / 256), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
+        else if (m * K <= MERKLE_COOP_MAX_PARENTS)   // few hashes: 12 lanes per hash for latency
             hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((m + 15) / 16), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
         else
             hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
@@ -176,20 +223,23 @@ static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_he
     return GLP_OK;
 }
 
-int merkle_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height, u32 K, size_t dig_stride) {
-    return build_levels(c, dev_digests, nleaves, cap_height, K, dig_stride);
+int merkle_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_height, u32 K, size_t dig_stride, int hasher) {
+    return build_levels(c, dev_digests, nleaves, cap_height, K, dig_stride, hasher);
 }
 
 // K > 1: K trees over K LDE matrices (stride lde_stride words) into K digest arrays (stride dig_stride words)
 int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_bits, int cap_height, u64 *dev_digests, u32 K,
-                    size_t lde_stride, size_t dig_stride) {
+                    size_t lde_stride, size_t dig_stride, int hasher) {
     const size_t N = (size_t)1 << (lg + rate_bits);
     if (cap_height < 0 || ((size_t)1 << cap_height) > N)
         return set_error(GLP_ERR_ARG, "cap_height=%d should be at most log2(leaves)=%d", cap_height, lg + rate_bits);
     GLP_REQUIRE(K >= 1 && K <= 65535, "batch of %u trees outside 1..65535", K);
     {
         StageScope st(c, "merkle_leaves", (double)N * K * (8.0 * ncols + 32.0));
-        if (N * K <= MERKLE_COOP_MAX_LEAVES)
+        if (hasher == GLP_HASH_KECCAK25)
+            hipLaunchKernelGGL(k_leaf_hash_lde_keccak, dim3((unsigned)((N + 255) / 256), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
+                               ncols, lg, rate_bits, lde_stride, dig_stride);
+        else if (N * K <= MERKLE_COOP_MAX_LEAVES)
             hipLaunchKernelGGL(k_leaf_hash_lde_coop, dim3((unsigned)((N + 15) / 16), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
                                ncols, lg, rate_bits, lde_stride, dig_stride);
         else
@@ -198,7 +248,7 @@ int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_
         GLP_HIP(hipGetLastError());
     }
     StageScope st(c, "merkle_levels", (double)N * K * 32.0 * 1.5);
-    return build_levels(c, dev_digests, N, cap_height, K, dig_stride);
+    return build_levels(c, dev_digests, N, cap_height, K, dig_stride, hasher);
 }
 
 int merkle_from_rows(glp_ctx *c, const u64 *dev_rows, size_t nleaves, u32 leaf_len, int cap_height, u64 *dev_digests) {

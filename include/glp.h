@@ -40,6 +40,9 @@ extern "C" {
 #define GLP_ERR_NOGPU (-4)       /* no gfx950 device visible */
 #define GLP_ERR_PROVE (-5)       /* prove: the transcript cannot continue (PoW search exhausted, zeta in the subgroup); verify: proof rejected */
 
+#define GLP_HASH_POSEIDON 0      /* PoseidonGoldilocksConfig */
+#define GLP_HASH_KECCAK25 1      /* KeccakGoldilocksConfig: KeccakHash<25> [REF src/hash/keccak256.rs:281] */
+
 typedef struct glp_ctx glp_ctx;
 typedef struct glp_batch glp_batch; /* plonky2 `PolynomialBatch`: coefficients + LDE + Merkle tree, device resident */
 
@@ -103,8 +106,6 @@ GLP_API int glp_batch_from_coeffs_device(glp_ctx *ctx, const uint64_t *dev_coeff
  * reference but one); GLP_HASH_KECCAK25 = KeccakGoldilocksConfig, `KeccakHash<25>` [REF src/hash/keccak256.rs:281]: Keccak-256
  * truncated to 25 bytes; such a digest occupies the same 4-word slot as a Poseidon HashOut (little-endian bytes, top 7 bytes of the
  * last word zero), so caps, paths and digest arrays keep their shapes.  The *_h entry points are the ones above with the hash named. */
-#define GLP_HASH_POSEIDON 0
-#define GLP_HASH_KECCAK25 1
 GLP_API int glp_batch_from_values_h(glp_ctx *ctx, const uint64_t *values, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
                                     uint32_t cap_height, uint32_t hasher, glp_batch **out);
 GLP_API int glp_batch_from_coeffs_h(glp_ctx *ctx, const uint64_t *coeffs, uint32_t ncols, uint32_t log_n, uint32_t rate_bits,
@@ -183,6 +184,10 @@ typedef struct {
     uint64_t circuit_digest[4];        /* verifier_only.circuit_digest; all-zero = let the library derive it */
     const uint64_t *constants;         /* [num_constants][n]    values on H (constant_vecs) */
     const uint64_t *sigmas;            /* [num_routed_wires][n] values on H (sigma_vecs) */
+    uint32_t hasher;                   /* GLP_HASH_POSEIDON (0) or GLP_HASH_KECCAK25: `GenericConfig::Hasher` of the proof (Merkle trees,
+                                          transcript, proof of work).  The public-input hash is the InnerHasher, Poseidon in both.
+                                          With GLP_HASH_KECCAK25 every digest in caps, paths and circuit_digest is a 25-byte value in
+                                          a 4-word slot (see GLP_HASH_KECCAK25 above) */
 } glp_circuit_desc;
 
 typedef struct glp_circuit glp_circuit;
@@ -307,6 +312,9 @@ GLP_API int glp_session_fri_final_poly(glp_session *s, uint64_t *coeffs_out /* [
  * observing w, squeezes an element with `bits` leading zero bits (fri_proof_of_work) */
 GLP_API int glp_pow_search(glp_ctx *ctx, const uint64_t sponge_state[12], const uint64_t *pending_inputs, uint32_t num_pending,
                            uint32_t bits, uint64_t *witness_out);
+/* the same for a transcript whose permutation is that of `hasher` (GLP_HASH_KECCAK25: KeccakPermutation) */
+GLP_API int glp_pow_search_h(glp_ctx *ctx, uint32_t hasher, const uint64_t sponge_state[12], const uint64_t *pending_inputs,
+                             uint32_t num_pending, uint32_t bits, uint64_t *witness_out);
 GLP_API int glp_session_queries(glp_session *s, uint64_t pow_witness, const uint64_t *indices, uint32_t num_indices);
 GLP_API int glp_session_proof(glp_session *s, uint64_t *proof_out /* glp_proof_words(circuit) */);
 GLP_API void glp_session_end(glp_session *s);

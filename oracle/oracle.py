@@ -271,16 +271,26 @@ def _batch_from_values(values, rate_bits=3, cap_height=4):
 
 # ---------------------------------------------------------------- Challenger
 class Challenger:
-    def __init__(self):
+    """plonky2's duplex `Challenger<F, H>`; hasher = 1: H = KeccakHash<25> (KeccakPermutation, digests observed as 7-byte chunks)."""
+    def __init__(self, hasher=0):
+        self.hasher = int(hasher)
         self._buf = C.create_string_buffer(lib().glo_challenger_size())
         lib().glo_challenger_init(self._buf)
 
     def observe(self, elems):
         e = _a(elems).reshape(-1)
-        lib().glo_challenger_observe(self._buf, _p(e), C.c_size_t(e.size))
+        with _Hasher(self.hasher):
+            lib().glo_challenger_observe(self._buf, _p(e), C.c_size_t(e.size))
+
+    def observe_hashes(self, digests):
+        """observe_hash / observe_cap: digests [count][4] of the configuration's hasher"""
+        d = _a(digests).reshape(-1, 4)
+        with _Hasher(self.hasher):
+            lib().glo_challenger_observe_hashes(self._buf, _p(d), C.c_size_t(d.shape[0]))
 
     def get(self):
-        return int(lib().glo_challenger_get(self._buf))
+        with _Hasher(self.hasher):
+            return int(lib().glo_challenger_get(self._buf))
 
     def get_n(self, n):
         return [self.get() for _ in range(n)]

@@ -38,7 +38,7 @@ class _CircuitDesc(C.Structure):
                                            "proof_of_work_bits", "num_query_rounds", "num_reductions")] +
                 [("reduction_arity_bits", C.c_uint32 * 16), ("num_gates", C.c_uint32), ("num_public_inputs", C.c_uint32),
                  ("gates", C.POINTER(_Gate)), ("k_is", C.c_void_p), ("circuit_digest", C.c_uint64 * 4),
-                 ("constants", C.c_void_p), ("sigmas", C.c_void_p)])
+                 ("constants", C.c_void_p), ("sigmas", C.c_void_p), ("hasher", C.c_uint32)])
 
 
 def library_path():
@@ -124,6 +124,7 @@ def load_library():
         "glp_session_fri_fold": [vp, vp],
         "glp_session_fri_final_poly": [vp, vp],
         "glp_pow_search": [vp, vp, vp, C.c_uint32, C.c_uint32, vp],
+        "glp_pow_search_h": [vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp],
         "glp_session_queries": [vp, C.c_uint64, vp, C.c_uint32],
         "glp_session_proof": [vp, vp],
         "glp_session_end": [vp],
@@ -405,6 +406,7 @@ def _desc_to_c(desc):
     if dig is not None:
         for i in range(4):
             d.circuit_digest[i] = int(dig[i])
+    d.hasher = int(getattr(desc, "hasher", 0))
     return d, (gates, k, const, sig)
 
 
@@ -453,6 +455,7 @@ class CircuitFile:
         d.sigmas = view(cd.sigmas, (d.num_routed_wires, n))
         dig = [int(cd.circuit_digest[i]) for i in range(4)]
         d.circuit_digest = np.array(dig, np.uint64) if any(dig) else None
+        d.hasher = int(cd.hasher)
         wp = L.glp_circuit_file_wires(self._h)
         self.has_witness = bool(wp)
         d.wires = view(wp, (d.num_wires, n)) if wp else None
@@ -667,8 +670,8 @@ class Session:
     def pow_search(self, sponge_state, pending_inputs, bits):
         st, pend = _a(sponge_state), _a(pending_inputs)
         w = C.c_uint64()
-        _chk(load_library().glp_pow_search(self.circuit.ctx._h, _p(st), _p(pend) if pend.size else None, pend.size, int(bits),
-                                           C.byref(w)))
+        _chk(load_library().glp_pow_search_h(self.circuit.ctx._h, int(getattr(self.circuit.desc, "hasher", 0)), _p(st),
+                                             _p(pend) if pend.size else None, pend.size, int(bits), C.byref(w)))
         return int(w.value)
 
     def queries(self, pow_witness, indices):

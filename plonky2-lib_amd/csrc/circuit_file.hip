@@ -22,7 +22,7 @@
 //   136 u32      num_gates
 //   140 u32      num_public_inputs
 //   144 u32      has_witness (0 / 1)
-//   148 u32      reserved = 0
+//   148 u32      hasher (GLP_HASH_POSEIDON = 0, GLP_HASH_KECCAK25 = 1; files written before the field existed hold 0)
 //   152 u64[4]   circuit_digest (all zero = derive it from the constants/sigmas cap)
 //   184 u64      checksum: FNV-1a 64 over every byte from header_bytes to the end of the file
 //   192 = header_bytes
@@ -49,7 +49,7 @@ struct Header {
     u32 version, header_bytes;
     u32 scalars[14];
     u32 arity[16];
-    u32 num_gates, num_public_inputs, has_witness, reserved;
+    u32 num_gates, num_public_inputs, has_witness, hasher;
     u64 digest[4];
     u64 checksum;
 };
@@ -108,7 +108,7 @@ int glp_circuit_file_write(const char *path, const glp_circuit_desc *d, const ui
     memcpy(h.scalars, sc, sizeof(sc));
     GLP_REQUIRE(d->num_reductions <= 16, "more than 16 FRI reductions");
     memcpy(h.arity, d->reduction_arity_bits, sizeof(h.arity));
-    h.num_gates = d->num_gates; h.num_public_inputs = d->num_public_inputs; h.has_witness = wires ? 1 : 0;
+    h.num_gates = d->num_gates; h.num_public_inputs = d->num_public_inputs; h.has_witness = wires ? 1 : 0; h.hasher = d->hasher;
     memcpy(h.digest, d->circuit_digest, 32);
     Sizes s;
     GLP_REQUIRE(sizes_of(h, s), "circuit dimensions outside what the file format holds");
@@ -150,7 +150,7 @@ int glp_circuit_file_open(const char *path, int verify_checksum, glp_circuit_fil
     memcpy(&h, m, sizeof(h));
     GLP_REQUIRE(memcmp(h.magic, MAGIC, 8) == 0, "%s: not a circuit file (bad magic)", path);
     if (h.version != VERSION) return set_error(GLP_ERR_UNSUPPORTED, "%s: circuit-file version %u, this build reads version %u", path, h.version, VERSION);
-    GLP_REQUIRE(h.header_bytes == HEADER_BYTES && h.has_witness <= 1 && h.scalars[13] <= 16, "%s: malformed header", path);
+    GLP_REQUIRE(h.header_bytes == HEADER_BYTES && h.has_witness <= 1 && h.scalars[13] <= 16 && h.hasher <= 1, "%s: malformed header", path);
     Sizes s;
     GLP_REQUIRE(sizes_of(h, s), "%s: circuit dimensions out of range", path);
     GLP_REQUIRE(s.total == f->len, "%s: %zu bytes, the header describes %zu (truncated or padded file)", path, f->len, s.total);
@@ -166,7 +166,7 @@ int glp_circuit_file_open(const char *path, int verify_checksum, glp_circuit_fil
     d.num_partial_products = h.scalars[7]; d.num_gate_constraints = h.scalars[8]; d.rate_bits = h.scalars[9]; d.cap_height = h.scalars[10];
     d.proof_of_work_bits = h.scalars[11]; d.num_query_rounds = h.scalars[12]; d.num_reductions = h.scalars[13];
     memcpy(d.reduction_arity_bits, h.arity, sizeof(h.arity));
-    d.num_gates = h.num_gates; d.num_public_inputs = h.num_public_inputs;
+    d.num_gates = h.num_gates; d.num_public_inputs = h.num_public_inputs; d.hasher = h.hasher;
     memcpy(d.circuit_digest, h.digest, 32);
     size_t o = HEADER_BYTES;
     d.gates = (const glp_gate *)(base + o); o += s.gates;

@@ -1054,6 +1054,31 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64 *vals, u64
     }
     if (live && l < 4) digests[4 * m + l] = x;
 }
+// K9a with KeccakHash<25>: hash_or_noop of the leaf's 2^(ab+1) elements (arity 2 already exceeds the 3 elements that are copied)
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_keccak(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab, size_t vals_bstride,
+                                                              size_t dig_bstride) {
+    vals += (size_t)blockIdx.y * vals_bstride; digests += (size_t)blockIdx.y * dig_bstride;
+    const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
+    const size_t Mp = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (Mp >= nleaves) return;
+    const size_t m = bitrev32((u32)Mp, lgL - ab);
+    const u32 arity = 1u << ab;
+    kec::Sponge s;
+    kec::sponge_init(s);
+    for (u32 t = 0; t < arity; t++) {
+        const size_t i = (size_t)bitrev32(t, ab) * nleaves + Mp;
+        const size_t pos = (i & (((size_t)1 << rb) - 1)) * ncur + (i >> rb);
+        kec::sponge_absorb(s, vals[pos]);
+        kec::sponge_absorb(s, vals[L + pos]);
+    }
+    kec::sponge_finish(s);
+    u64 d[4];
+    kec::sponge_digest25(s, d);
+    ulonglong2 d0, d1;
+    d0.x = d[0]; d0.y = d[1]; d1.x = d[2]; d1.y = d[3];
+    reinterpret_cast<ulonglong2 *>(digests + 4 * m)[0] = d0;
+    reinterpret_cast<ulonglong2 *>(digests + 4 * m)[1] = d1;
+}
 // K9b: fold coefficients (bit-reversed layout): new[p'] = sum_t beta^t old[bitrev(t) * nnew + p']
 // batch (beta_b != nullptr, blockIdx.y = proof): beta from beta_b[proof][2]; coefficient arrays [proof][2][n]
 __global__ __launch_bounds__(256) void k_fri_fold(const u64 *oldc, u64 *newc, ext2 beta, u32 lg_old, u32 ab, const u64 *beta_b) {
@@ -1090,13 +1115,15 @@ __global__ void k_fri_gather_leaf(const u64 *vals, u32 lgL, u32 rb, u32 ab, cons
 
 // K10: proof-of-work grinding; smallest candidate in [base, base + count) whose response has `bits` leading zeros
 struct PowArgs { u64 st[12]; u32 pos, bits; u64 base; unsigned long long *best; };
+template <int HASHER>
 __global__ __launch_bounds__(256) void k_pow(PowArgs a) {
     const u64 cand = a.base + (u64)blockIdx.x * 256 + threadIdx.x;
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = a.st[i];
-    s[a.pos] = cand;        // candidates stay far below p
-    pos::permute(s);
+#pragma unroll
+    for (int i = 0; i < 8; i++) if ((u32)i == a.pos) s[i] = cand;        // candidates stay far below p
+    if constexpr (HASHER == GLP_HASH_KECCAK25) kec::permute(s); else pos::permute(s);
     if (a.bits == 0 || (s[7] >> (64 - a.bits)) == 0) atomicMin(a.best, (unsigned long long)cand);
 }
 
@@ -1108,6 +1135,7 @@ __global__ __launch_bounds__(256) void k_pow(PowArgs a) {
 // hence the result is the smallest witness regardless of scheduling.  Termination: a proof is finished once best <= next
 // (a witness exists below 2^40 with overwhelming probability; the hand-out stops there in any case), and a workgroup exits
 // after one full pass over the proofs finds none unfinished.
+template <int HASHER>
 __global__ __launch_bounds__(256) void k_pow_batch(const u64 *st_b, const u32 *pos_b, u32 bits, unsigned long long *best,
                                                    unsigned long long *next, u32 K) {
     __shared__ unsigned long long sh_base;
@@ -1133,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_pow_batch(const u64 *st_b, const u32 *p
         const u32 pos = pos_b[pk];
         const u64 cand = base + threadIdx.x;
         for (u32 i = 0; i < 8; i++) if (i == pos) s[i] = cand;      // candidates stay far below p
-        pos::permute(s);
+        if constexpr (HASHER == GLP_HASH_KECCAK25) kec::permute(s); else pos::permute(s);
         if (bits == 0 || (s[7] >> (64 - bits)) == 0) atomicMin(best + pk, (unsigned long long)cand);
     }
 }
@@ -1210,6 +1238,7 @@ struct glp_session {
     const int lg, rb;
     const size_t n, N;
     const u32 nch, nr, nw, nc, qdf, npp, capn, nzp;
+    const int hasher;
     Tmp tmp;
     u64 *owned_wires = nullptr;        // device copy made by begin() when the caller passed host memory
     const u64 *dev_wires = nullptr;
@@ -1235,7 +1264,7 @@ struct glp_session {
           n((size_t)1 << circ->d.degree_bits), N(((size_t)1 << circ->d.degree_bits) << circ->d.rate_bits),
           nch(circ->d.num_challenges), nr(circ->d.num_routed_wires), nw(circ->d.num_wires), nc(circ->d.num_constants),
           qdf(circ->d.quotient_degree_factor), npp(circ->d.num_partial_products), capn(1u << circ->d.cap_height),
-          nzp(circ->d.num_challenges * (1 + circ->d.num_partial_products)), tmp(ctx) {}
+          nzp(circ->d.num_challenges * (1 + circ->d.num_partial_products)), hasher((int)circ->d.hasher), tmp(ctx) {}
     ~glp_session() { if (owned_wires) { (void)hipStreamSynchronize(c->stream); c->release(owned_wires); } }
     u64 *proof() { return proof_words.data(); }
 
@@ -1248,7 +1277,7 @@ struct glp_session {
         dev_wires = wires_dev;
         host_hash_no_pad(public_inputs, d.num_public_inputs, pih);
         if (d.num_public_inputs) memcpy(proof() + L.pis, public_inputs, (size_t)d.num_public_inputs * 8);
-        GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b, host_wires));
+        GLP_TRY(batch_build(c, dev_wires, BATCH_VALUES, nw, lg, rb, (int)d.cap_height, &wb.b, host_wires, 1, hasher));
         GLP_TRY(batch_cap_host(c, wb.b, cap));
         memcpy(proof() + L.caps, cap.data(), capn * 32);
         stage = S_WIRES;
@@ -1283,7 +1312,7 @@ struct glp_session {
             hipLaunchKernelGGL(k_pp_apply, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, nch, npp, (size_t)0);
             GLP_HIP(hipGetLastError());
         }
-        GLP_TRY(batch_build(c, zp, BATCH_VALUES, nzp, lg, rb, (int)d.cap_height, &zb.b));
+        GLP_TRY(batch_build(c, zp, BATCH_VALUES, nzp, lg, rb, (int)d.cap_height, &zb.b, nullptr, 1, hasher));
         GLP_TRY(batch_cap_host(c, zb.b, cap));
         memcpy(proof() + L.caps + capn * 4, cap.data(), capn * 32);
         stage = S_ZS;
@@ -1397,7 +1426,7 @@ struct glp_session {
             hipLaunchKernelGGL(k_quotient_combine, dim3(nblk(n), nch), dim3(256), 0, c->stream, q);
             GLP_HIP(hipGetLastError());
         }
-        GLP_TRY(batch_build(c, qc, BATCH_COEFFS_BITREV, nch * qdf, lg, rb, (int)d.cap_height, &qb.b));
+        GLP_TRY(batch_build(c, qc, BATCH_COEFFS_BITREV, nch * qdf, lg, rb, (int)d.cap_height, &qb.b, nullptr, 1, hasher));
         GLP_TRY(batch_cap_host(c, qb.b, cap));
         memcpy(proof() + L.caps + 2 * capn * 4, cap.data(), capn * 32);
         stage = S_QUOTIENT;
@@ -1502,14 +1531,17 @@ struct glp_session {
         GLP_TRY(tmp.get(&ly.vals, 2 * Lsz));
         GLP_TRY(tmp.get(&ly.dig, merkle_num_digests(nleaves, (int)d.cap_height) * 4));
         GLP_TRY(lde_coeffs(c, cur, ly.vals, 2, lgcur, rb, shift));
-        if (nleaves <= 8192)
+        if (hasher == GLP_HASH_KECCAK25)
+            hipLaunchKernelGGL(k_fri_leaf_hash_keccak, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab, (size_t)0,
+                               (size_t)0);
+        else if (nleaves <= 8192)
             hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((nleaves + 15) / 16)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
                                (u32)rb, ab, (size_t)0, (size_t)0);
         else
             hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab, (size_t)0,
                                (size_t)0);
         GLP_HIP(hipGetLastError());
-        GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height));
+        GLP_TRY(merkle_levels(c, ly.dig, nleaves, (int)d.cap_height, 1, 0, hasher));
         cap.resize((size_t)capn * 4);
         GLP_TRY(d2h(c, cap.data(), ly.dig + 4 * merkle_cap_offset(nleaves, (int)d.cap_height), (size_t)capn * 32));
         memcpy(proof() + L.fri_caps + (size_t)r * capn * 4, cap.data(), (size_t)capn * 32);
@@ -1594,7 +1626,7 @@ struct glp_session {
 constexpr u32 POW_MAX_BITS = 32;
 // K10: smallest witness w >= 0 such that the sponge (state + pending inputs + w) squeezes a value with `bits` leading
 // zeros.  The search covers candidates in increasing order, so the result does not depend on launch geometry.
-static int pow_search(glp_ctx *c, const u64 st[12], const u64 *pending, u32 npending, u32 bits, u64 *witness) {
+static int pow_search(glp_ctx *c, const u64 st[12], const u64 *pending, u32 npending, u32 bits, u64 *witness, int hasher = GLP_HASH_POSEIDON) {
     StageScope stg(c, "fri_pow", 0.0);
     GLP_REQUIRE(npending < 8, "proof of work: %u pending inputs (the rate is 8)", npending);
     PowArgs a;
@@ -1613,7 +1645,8 @@ static int pow_search(glp_ctx *c, const u64 st[12], const u64 *pending, u32 npen
         if (base >= (1ull << 40)) return set_error(GLP_ERR_PROVE, "Proof of work failed. This is highly unlikely!");
         GLP_TRY(h2d(c, best, &none, 8));
         a.base = base;
-        hipLaunchKernelGGL(k_pow, dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, a);
+        if (hasher == GLP_HASH_KECCAK25) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow<GLP_HASH_KECCAK25>), dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pow<GLP_HASH_POSEIDON>), dim3((unsigned)(batch / 256)), dim3(256), 0, c->stream, a);
         GLP_HIP(hipGetLastError());
         GLP_TRY(d2h(c, &found, best, 8));
     }
@@ -1629,18 +1662,18 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
     const Layout &L = cc->L;
     const u32 nch = s.nch, nr = s.nr, nw = s.nw, nc = s.nc, qdf = s.qdf, npp = s.npp, capn = s.capn;
     GLP_TRY(s.begin(dev_wires, public_inputs, host_wires));
-    Challenger ch;
-    ch.observe(cc->digest, 4);
-    ch.observe(s.pih, 4);
-    ch.observe(s.cap.data(), capn * 4);
+    Challenger ch((int)d.hasher);
+    ch.observe_hashes(cc->digest, 1);
+    ch.observe(s.pih, 4);                       // InnerHasher (Poseidon) HashOut
+    ch.observe_hashes(s.cap.data(), capn);
     u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
     for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
     for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
     GLP_TRY(s.partial_products(betas, gammas));
-    ch.observe(s.cap.data(), capn * 4);
+    ch.observe_hashes(s.cap.data(), capn);
     for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
     GLP_TRY(s.quotient(alphas));
-    ch.observe(s.cap.data(), capn * 4);
+    ch.observe_hashes(s.cap.data(), capn);
     GLP_TRY(s.open_at(ch.get_ext()));
     {
         const u64 *op = s.proof() + L.openings;
@@ -1652,13 +1685,13 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
     GLP_TRY(s.fri_combine(ch.get_ext()));
     for (u32 r = 0; r < d.num_reductions; r++) {
         GLP_TRY(s.fri_commit_layer());
-        ch.observe(s.cap.data(), (size_t)capn * 4);
+        ch.observe_hashes(s.cap.data(), capn);
         GLP_TRY(s.fri_fold(ch.get_ext()));
     }
     GLP_TRY(s.fri_final_poly());
     ch.observe(s.proof() + L.final_poly, 2 * L.final_len);
     u64 found;
-    GLP_TRY(pow_search(c, ch.st, ch.in, (u32)ch.nin, d.proof_of_work_bits, &found));
+    GLP_TRY(pow_search(c, ch.st, ch.in, (u32)ch.nin, d.proof_of_work_bits, &found, (int)d.hasher));
     ch.observe(&found, 1);
     const u64 resp = ch.get();
     if (d.proof_of_work_bits && (resp >> (64 - d.proof_of_work_bits)) != 0)
@@ -1672,24 +1705,28 @@ static int prove_impl(glp_ctx *c, const glp_circuit *cc, const u64 *dev_wires, c
 
 // ---- byte format (util/serialization.rs): words little-endian, u8 sibling count before each Merkle path
 namespace {
-// calls f(offset_words, count_words, is_path_start) for the pieces of a proof in order
+// calls f(offset_words, count_words, kind) for the pieces of a proof in order.  PW_FIELD: field elements; PW_DIGESTS: digests of
+// the proof's hasher, 4 words each (caps); PW_PATH: a Merkle path (digests, preceded by a one-byte sibling count on the wire)
+enum { PW_FIELD = 0, PW_DIGESTS = 1, PW_PATH = 2 };
 template <class F> void walk_proof(const glp_circuit *cc, F f) {
     const Layout &L = cc->L;
     const glp_circuit_desc &d = cc->d;
-    f((size_t)0, L.queries, false);                     // caps, openings, commit-phase caps
+    f((size_t)0, L.openings, PW_DIGESTS);                                   // wires, Z / partial products, quotient caps
+    f(L.openings, L.fri_caps - L.openings, PW_FIELD);                       // openings
+    f(L.fri_caps, L.queries - L.fri_caps, PW_DIGESTS);                      // commit-phase caps
     for (u32 q = 0; q < d.num_query_rounds; q++) {
         size_t o = L.queries + (size_t)q * L.query_stride;
         for (int k = 0; k < 4; k++) {
-            f(o, (size_t)L.oracle_cols[k], false); o += L.oracle_cols[k];
-            f(o, 4 * (size_t)L.depth0, true); o += 4 * (size_t)L.depth0;
+            f(o, (size_t)L.oracle_cols[k], PW_FIELD); o += L.oracle_cols[k];
+            f(o, 4 * (size_t)L.depth0, PW_PATH); o += 4 * (size_t)L.depth0;
         }
         for (u32 r = 0; r < d.num_reductions; r++) {
             const size_t ev = (size_t)2 << d.reduction_arity_bits[r];
-            f(o, ev, false); o += ev;
-            f(o, 4 * (size_t)L.step_depth[r], true); o += 4 * (size_t)L.step_depth[r];
+            f(o, ev, PW_FIELD); o += ev;
+            f(o, 4 * (size_t)L.step_depth[r], PW_PATH); o += 4 * (size_t)L.step_depth[r];
         }
     }
-    f(L.final_poly, L.total - L.final_poly, false);     // final poly, pow witness, public inputs
+    f(L.final_poly, L.total - L.final_poly, PW_FIELD);     // final poly, pow witness, public inputs
 }
 }  // namespace
 
@@ -1787,6 +1824,7 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
     const glp_circuit_desc &d = *desc;
     GLP_REQUIRE(d.gates && d.k_is && d.constants && d.sigmas, "null array in circuit description");
     GLP_REQUIRE(d.num_challenges >= 1 && d.num_challenges <= (u32)MAXCH, "num_challenges=%u outside 1..%d", d.num_challenges, MAXCH);
+    if (d.hasher != GLP_HASH_POSEIDON && d.hasher != GLP_HASH_KECCAK25) return set_error(GLP_ERR_UNSUPPORTED, "hasher %u is not one of GLP_HASH_*", d.hasher);
     GLP_REQUIRE(d.rate_bits >= 1 && d.rate_bits <= 4, "rate_bits=%u outside 1..4", d.rate_bits);
     GLP_REQUIRE(d.num_routed_wires <= d.num_wires && d.num_routed_wires > 0, "bad wire counts");
     if ((int)d.degree_bits > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "degree_bits=%u > %d", d.degree_bits, NTT_MAX_LG);
@@ -1903,7 +1941,7 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
             hipError_t e = hipMemcpyAsync(csv + (size_t)nc * n, cc->dev_sigmas, (size_t)nr * n * 8, hipMemcpyDeviceToDevice, c->stream);
             if (e != hipSuccess) rc = set_error(GLP_ERR_HIP, "D2D copy: %s", hipGetErrorString(e));
         }
-        if (rc == GLP_OK) rc = batch_build(c, csv, BATCH_VALUES, nc + nr, (int)d.degree_bits, (int)d.rate_bits, (int)d.cap_height, &cc->cs);
+        if (rc == GLP_OK) rc = batch_build(c, csv, BATCH_VALUES, nc + nr, (int)d.degree_bits, (int)d.rate_bits, (int)d.cap_height, &cc->cs, nullptr, 1, (int)d.hasher);
         (void)hipStreamSynchronize(c->stream);
         c->release(v);
         GLP_TRY(rc);
@@ -1911,7 +1949,17 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
     GLP_TRY(batch_cap_host(c, cc->cs, cc->cs_cap));
     bool zero = true;
     for (int i = 0; i < 4; i++) zero = zero && d.circuit_digest[i] == 0;
-    if (zero) {
+    if (zero && d.hasher == GLP_HASH_KECCAK25) {
+        // the same recipe with C::Hasher = KeccakHash<25>: every hash enters as its four 7-byte chunks (BytesHash::to_vec)
+        u64 pad[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, ds[4], e[4];
+        kec::host_hash_no_pad(pad, 12, ds);
+        std::vector<u64> parts;
+        for (size_t i = 0; i < cc->cs_cap.size(); i += 4) { kec::digest_to_elements(&cc->cs_cap[i], e); parts.insert(parts.end(), e, e + 4); }
+        kec::digest_to_elements(ds, e);
+        parts.insert(parts.end(), e, e + 4);
+        parts.push_back(d.degree_bits);
+        kec::host_hash_no_pad(parts.data(), parts.size(), cc->digest);
+    } else if (zero) {
         // hash_pad([]) = hash_no_pad([1, 0 x 10, 1]); digest = hash_no_pad(cap ++ that ++ [degree_bits])
         u64 pad[12] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1}, ds[4];
         host_hash_no_pad(pad, 12, ds);
@@ -1939,22 +1987,28 @@ int glp_circuit_constants_sigmas_cap(const glp_circuit *cc, uint64_t *cap_out) {
 }
 size_t glp_proof_words(const glp_circuit *cc) { return cc ? cc->L.total : 0; }
 
+// bytes of one digest on the wire: a Poseidon HashOut is 4 field elements, a KeccakHash<25> digest 25 bytes
+static size_t digest_wire_bytes(const glp_circuit *cc) { return cc->d.hasher == GLP_HASH_KECCAK25 ? 25 : 32; }
+
 size_t glp_proof_bytes_len(const glp_circuit *cc) {
     if (!cc) return 0;
-    size_t paths = 0;
-    walk_proof(cc, [&](size_t, size_t, bool path) { paths += path ? 1 : 0; });
-    return cc->L.total * 8 + paths;
+    size_t bytes = 0;
+    const size_t db = digest_wire_bytes(cc);
+    walk_proof(cc, [&](size_t, size_t cnt, int kind) { bytes += kind == PW_FIELD ? cnt * 8 : (cnt / 4) * db + (kind == PW_PATH ? 1 : 0); });
+    return bytes;
 }
 
 int glp_proof_to_bytes(const glp_circuit *cc, const uint64_t *words, uint8_t *out, size_t len) {
     GLP_REQUIRE(cc && words && out, "null argument");
     GLP_REQUIRE(len == glp_proof_bytes_len(cc), "bytes_len must equal glp_proof_bytes_len()");
     size_t o = 0;
-    walk_proof(cc, [&](size_t off, size_t cnt, bool path) {
-        if (path) out[o++] = (uint8_t)(cnt / 4);
+    const bool kec25 = cc->d.hasher == GLP_HASH_KECCAK25;
+    walk_proof(cc, [&](size_t off, size_t cnt, int kind) {
+        if (kind == PW_PATH) out[o++] = (uint8_t)(cnt / 4);
         for (size_t i = 0; i < cnt; i++) {
             const u64 w = words[off + i];
-            for (int b = 0; b < 8; b++) out[o++] = (uint8_t)(w >> (8 * b));
+            const int nb = (kind != PW_FIELD && kec25 && (i & 3) == 3) ? 1 : 8;        // last word of a 25-byte digest: one byte
+            for (int b = 0; b < nb; b++) out[o++] = (uint8_t)(w >> (8 * b));
         }
     });
     return GLP_OK;
@@ -1965,12 +2019,15 @@ int glp_proof_from_bytes(const glp_circuit *cc, const uint8_t *in, size_t len, u
     GLP_REQUIRE(len == glp_proof_bytes_len(cc), "byte length does not match this circuit");
     size_t o = 0;
     int bad = 0;
-    walk_proof(cc, [&](size_t off, size_t cnt, bool path) {
-        if (path && in[o++] != (uint8_t)(cnt / 4)) bad = 1;
+    const bool kec25 = cc->d.hasher == GLP_HASH_KECCAK25;
+    walk_proof(cc, [&](size_t off, size_t cnt, int kind) {
+        if (kind == PW_PATH && in[o++] != (uint8_t)(cnt / 4)) bad = 1;
         for (size_t i = 0; i < cnt; i++) {
+            const bool dig = kind != PW_FIELD && kec25;
+            const int nb = (dig && (i & 3) == 3) ? 1 : 8;
             u64 w = 0;
-            for (int b = 0; b < 8; b++) w |= (u64)in[o++] << (8 * b);
-            if (w >= glf::P) bad = 2;
+            for (int b = 0; b < nb; b++) w |= (u64)in[o++] << (8 * b);
+            if (!dig && w >= glf::P) bad = 2;                // field elements and Poseidon digests are canonical; Keccak digests are bytes
             words[off + i] = w;
         }
     });
@@ -2061,6 +2118,15 @@ int glp_pow_search(glp_ctx *c, const uint64_t sponge_state[12], const uint64_t *
                 POW_MAX_BITS);
     GLP_TRY(bind(c));
     return pow_search(c, sponge_state, pending_inputs, num_pending, bits, witness_out);
+}
+int glp_pow_search_h(glp_ctx *c, uint32_t hasher, const uint64_t sponge_state[12], const uint64_t *pending_inputs, uint32_t num_pending,
+                     uint32_t bits, uint64_t *witness_out) {
+    GLP_REQUIRE(c && sponge_state && witness_out && (pending_inputs || num_pending == 0), "null argument");
+    GLP_REQUIRE(bits <= POW_MAX_BITS, "proof_of_work_bits=%u: this build searches at most 2^40 candidates and accepts up to %u bits", bits,
+                POW_MAX_BITS);
+    if (hasher != GLP_HASH_POSEIDON && hasher != GLP_HASH_KECCAK25) return set_error(GLP_ERR_UNSUPPORTED, "hasher %u is not one of GLP_HASH_*", hasher);
+    GLP_TRY(bind(c));
+    return pow_search(c, sponge_state, pending_inputs, num_pending, bits, witness_out, (int)hasher);
 }
 int glp_session_queries(glp_session *s, uint64_t pow_witness, const uint64_t *indices, uint32_t num_indices) {
     GLP_SESSION_ENTER(s);

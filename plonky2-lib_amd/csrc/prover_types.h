@@ -6,6 +6,7 @@
 #include <vector>
 #include "batch.h"
 #include "common.h"
+#include "keccak.h"
 #include "poseidon.h"
 
 using namespace glp;
@@ -47,12 +48,20 @@ struct glp_circuit {
 // ------------------------------------------------------------------------------------------ transcript
 struct Challenger {   // iop/challenger.rs, overwrite-mode duplex sponge; challenges pop from the END of the rate
     u64 st[12]; u64 in[8]; int nin = 0; u64 out[8]; int nout = 0;
-    Challenger() { memset(st, 0, sizeof(st)); }
+    int hasher = GLP_HASH_POSEIDON;      // H::Permutation: Poseidon, or KeccakPermutation (hash chain, keccak.h)
+    explicit Challenger(int hasher_ = GLP_HASH_POSEIDON) : hasher(hasher_) { memset(st, 0, sizeof(st)); }
     void duplex() {
         for (int i = 0; i < nin; i++) st[i] = in[i];
         nin = 0;
-        pos::permute(st);
+        if (hasher == GLP_HASH_KECCAK25) kec::permute(st); else pos::permute(st);
         memcpy(out, st, 64); nout = 8;
+    }
+    // observe_hash / observe_cap for digests of the proof's hasher: a HashOut is its 4 elements, a BytesHash<25> its four 7-byte chunks
+    void observe_hashes(const u64 *digests, size_t count) {
+        for (size_t i = 0; i < count; i++) {
+            if (hasher == GLP_HASH_KECCAK25) { u64 e[4]; kec::digest_to_elements(digests + 4 * i, e); observe(e, 4); }
+            else observe(digests + 4 * i, 4);
+        }
     }
     void observe(const u64 *e, size_t n) {
         for (size_t i = 0; i < n; i++) { nout = 0; in[nin++] = e[i]; if (nin == 8) duplex(); }

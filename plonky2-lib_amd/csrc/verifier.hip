@@ -247,13 +247,16 @@ size_t brev(size_t x, int bits) {
 }
 
 // hash/merkle_proofs.rs verify_merkle_proof_to_cap
-bool merkle_ok(const u64 *leaf, size_t ncols, size_t index, const u64 *cap, const u64 *path, u32 depth) {
+bool merkle_ok(int hasher, const u64 *leaf, size_t ncols, size_t index, const u64 *cap, const u64 *path, u32 depth) {
     u64 cur[4] = {0, 0, 0, 0};
-    if (ncols <= 4) for (size_t i = 0; i < ncols; i++) cur[i] = leaf[i];       // hash_or_noop
+    const bool kec25 = hasher == GLP_HASH_KECCAK25;
+    if (kec25) kec::host_hash_or_noop(leaf, ncols, cur);
+    else if (ncols <= 4) for (size_t i = 0; i < ncols; i++) cur[i] = leaf[i];       // hash_or_noop
     else host_hash_no_pad(leaf, ncols, cur);
     for (u32 d = 0; d < depth; d++) {
         u64 nxt[4];
-        if (index & 1) pos::two_to_one(path + 4 * d, cur, nxt); else pos::two_to_one(cur, path + 4 * d, nxt);
+        if (kec25) { if (index & 1) kec::two_to_one(path + 4 * d, cur, nxt); else kec::two_to_one(cur, path + 4 * d, nxt); }
+        else if (index & 1) pos::two_to_one(path + 4 * d, cur, nxt); else pos::two_to_one(cur, path + 4 * d, nxt);
         memcpy(cur, nxt, 32);
         index >>= 1;
     }
@@ -269,22 +272,44 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
     const u32 qdf = d.quotient_degree_factor, npp = d.num_partial_products, capn = 1u << d.cap_height;
     const u32 nchunks = npp + 1;
 #define FAIL(...) return set_error(GLP_ERR_PROVE, __VA_ARGS__)
-    for (size_t i = 0; i < L.total; i++)
-        if (proof[i] >= P) FAIL("proof word %zu is not a canonical field element", i);
+    {   // field elements (and Poseidon digests) must be canonical; a KeccakHash<25> digest is 25 bytes in a 4-word slot
+        const bool kec25 = d.hasher == GLP_HASH_KECCAK25;
+        const size_t dig_lo[2] = {0, L.fri_caps}, dig_hi[2] = {L.openings, L.queries};        // cap regions
+        auto in_caps = [&](size_t i) { return (i >= dig_lo[0] && i < dig_hi[0]) || (i >= dig_lo[1] && i < dig_hi[1]); };
+        std::vector<unsigned char> is_dig(kec25 ? L.total : 0, 0);
+        if (kec25) {
+            for (size_t i = 0; i < L.queries; i++) is_dig[i] = in_caps(i);
+            for (u32 q = 0; q < d.num_query_rounds; q++) {
+                size_t o = L.queries + (size_t)q * L.query_stride;
+                for (int k = 0; k < 4; k++) { o += L.oracle_cols[k]; for (size_t j = 0; j < 4 * (size_t)L.depth0; j++) is_dig[o + j] = 1; o += 4 * (size_t)L.depth0; }
+                for (u32 r = 0; r < d.num_reductions; r++) {
+                    o += (size_t)2 << d.reduction_arity_bits[r];
+                    for (size_t j = 0; j < 4 * (size_t)L.step_depth[r]; j++) is_dig[o + j] = 1;
+                    o += 4 * (size_t)L.step_depth[r];
+                }
+            }
+        }
+        size_t run = 0;
+        for (size_t i = 0; i < L.total; i++) {
+            if (kec25 && is_dig[i]) { if ((run & 3) == 3 && proof[i] > 0xFF) FAIL("digest at word %zu is longer than 25 bytes", i - 3); run++; continue; }
+            run = 0;
+            if (proof[i] >= P) FAIL("proof word %zu is not a canonical field element", i);
+        }
+    }
 
     // ---- transcript (plonk/get_challenges.rs)
     u64 pih[4];
     host_hash_no_pad(proof + L.pis, d.num_public_inputs, pih);
-    Challenger ch;
-    ch.observe(cc->digest, 4);
+    Challenger ch((int)d.hasher);
+    ch.observe_hashes(cc->digest, 1);
     ch.observe(pih, 4);
-    ch.observe(proof + L.caps, capn * 4);
+    ch.observe_hashes(proof + L.caps, capn);
     u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
     for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
     for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
-    ch.observe(proof + L.caps + capn * 4, capn * 4);
+    ch.observe_hashes(proof + L.caps + capn * 4, capn);
     for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
-    ch.observe(proof + L.caps + 2 * capn * 4, capn * 4);
+    ch.observe_hashes(proof + L.caps + 2 * capn * 4, capn);
     const E zeta(ch.get_ext());
     const u64 *op = proof + L.openings;
     const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;
@@ -294,7 +319,7 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
     const E fri_alpha(ch.get_ext());
     std::vector<E> fri_betas(d.num_reductions);
     for (u32 r = 0; r < d.num_reductions; r++) {
-        ch.observe(proof + L.fri_caps + (size_t)r * capn * 4, capn * 4);
+        ch.observe_hashes(proof + L.fri_caps + (size_t)r * capn * 4, capn);
         fri_betas[r] = E(ch.get_ext());
     }
     ch.observe(proof + L.final_poly, 2 * (size_t)L.final_len);
@@ -373,7 +398,7 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
         const u64 *evals[4];
         for (int k = 0; k < 4; k++) {
             evals[k] = w;
-            if (!merkle_ok(w, L.oracle_cols[k], x_index, caps4[k], w + L.oracle_cols[k], L.depth0))
+            if (!merkle_ok((int)d.hasher, w, L.oracle_cols[k], x_index, caps4[k], w + L.oracle_cols[k], L.depth0))
                 FAIL("Invalid Merkle proof (query %u, initial tree %d)", q, k);
             w += L.oracle_cols[k] + 4 * (size_t)L.depth0;
         }
@@ -417,7 +442,7 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
                 }
                 old_eval = acc;
             }
-            if (!merkle_ok(ev, 2 * (size_t)arity, coset_index, proof + L.fri_caps + (size_t)r * capn * 4, path, L.step_depth[r]))
+            if (!merkle_ok((int)d.hasher, ev, 2 * (size_t)arity, coset_index, proof + L.fri_caps + (size_t)r * capn * 4, path, L.step_depth[r]))
                 FAIL("Invalid Merkle proof (query %u, reduction %u)", q, r);
             for (u32 i = 0; i < ab; i++) subgroup_x = sqr(subgroup_x);
             x_index = coset_index;

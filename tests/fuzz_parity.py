@@ -53,7 +53,10 @@ def random_case(rng):
                                    ecdsa_gate_rows=gate_rows, ecdsa_gate_subset=subset)
     if sum(desc.reduction_arity_bits) > desc.degree_bits:      # family fixed its own trace length: same plonky2 assertion
         return random_case(rng)
-    return desc, dict(family=family, lg=int(desc.degree_bits), wide=wide, npi=len(desc.public_inputs), gate_rows=gate_rows, **kw)
+    hasher = int(rng.random() < 0.3)                            # KeccakGoldilocksConfig: Merkle hasher, transcript permutation, PoW
+    if hasher:
+        desc.hasher, desc.circuit_digest = 1, None
+    return desc, dict(family=family, lg=int(desc.degree_bits), wide=wide, npi=len(desc.public_inputs), gate_rows=gate_rows, hasher=hasher, **kw)
 
 
 def main():
@@ -72,7 +75,7 @@ def main():
         ok = rc == 0 and (got == ref).all() and oc.verify(got) == 0 and gc.verify(got)
         bad = got.copy()
         pos = int(rng.integers(0, len(bad)))
-        bad[pos] = (int(bad[pos]) + 1) % glp.P
+        bad[pos] = (int(bad[pos]) ^ 1) if info["hasher"] else (int(bad[pos]) + 1) % glp.P      # Keccak digests are bytes, not field elements
         ok = ok and (not gc.verify(bad)) and oc.verify(bad) != 0
         # row-local witness generation: scramble what the generators derive, regenerate on the GPU and with the oracle
         from test_oracle_witness import scramble_derived

@@ -45,6 +45,28 @@ def test_round_trip(tmp_path, make):
         _same(cf.desc, desc, with_witness=False)
 
 
+def test_hasher_field(tmp_path):
+    """Header word 148: GenericConfig::Hasher of the circuit (0 Poseidon, 1 KeccakHash<25>); anything else is a malformed header."""
+    import struct
+    desc = synth.zkdsa_circuit(3)
+    path = str(tmp_path / "h.glpc")
+    glp.write_circuit_file(path, desc)
+    raw = bytearray(open(path, "rb").read())
+    assert struct.unpack_from("<I", raw, 148)[0] == 0
+    with glp.CircuitFile(path) as cf:
+        assert cf.desc.hasher == 0
+    desc.hasher = 1
+    glp.write_circuit_file(path, desc)
+    raw = bytearray(open(path, "rb").read())
+    assert struct.unpack_from("<I", raw, 148)[0] == 1
+    with glp.CircuitFile(path) as cf:
+        assert cf.desc.hasher == 1
+    struct.pack_into("<I", raw, 148, 7)
+    open(path, "wb").write(raw)
+    with pytest.raises(glp.GlpError):
+        glp.CircuitFile(path)
+
+
 def test_committed_sample_file():
     """tests/golden/zkdsa_2_3.glpc (written by make_golden.py): the reference's simple-signature circuit
     [REF src/zkdsa/circuits/mod.rs:24-43] with its witness; the header fields are checked byte by byte against the layout

@@ -35,10 +35,14 @@ def parse():
     ap.add_argument("--log-n", type=int, default=20, help="trace rows = 2^log_n (headline: 20)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=13, help="rows of the whole-prove() leg of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ecdsa", choices=["ecdsa", "zkdsa-batch"],
+    ap.add_argument("--workload", default="ecdsa", choices=["ecdsa", "zkdsa-batch", "keccak256"],
                     help="ecdsa: the headline 2^20-row proof (default); zkdsa-batch: BASELINE config 5, a batch of independent "
-                         "simple-signature proofs sharded over the ranks")
-    ap.add_argument("--batch", type=int, default=256, help="zkdsa-batch: proofs in the whole batch")
+                         "simple-signature proofs sharded over the ranks; keccak256: BASELINE config 2, the reference's Keccak-256 "
+                         "circuit (real gadget wiring, plonky2-lib_amd/gadgets.py) on a batch of messages")
+    ap.add_argument("--batch", type=int, default=None, help="zkdsa-batch / keccak256: proofs in the whole batch (default 256 / 16)")
+    ap.add_argument("--keccak-blocks", type=int, default=1, help="keccak256: rate blocks of the circuit (1: 2^13 rows, 4: 2^15 rows)")
+    ap.add_argument("--hasher", default="poseidon", choices=["poseidon", "keccak"],
+                    help="keccak256: PoseidonGoldilocksConfig or KeccakGoldilocksConfig [REF src/hash/keccak256.rs:216,281]")
     ap.add_argument("--threads", type=int, default=2, help="zkdsa-batch: sub-batches in flight per GPU (own context / stream / host thread each)")
     ap.add_argument("--sub-batch", type=int, default=128, help="zkdsa-batch: proofs per glp_prove_batch call")
     ap.add_argument("--per-proof", action="store_true", help="zkdsa-batch: one glp_prove call per proof (the round-1 path), for comparison")
@@ -213,9 +217,21 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
     transcripts overlap another's device stages.  --per-proof restores the r01 path (one glp_prove per proof) for comparison."""
     import threading
     import numpy as np
+    keccak = a.workload == "keccak256"
+    if a.batch is None:
+        a.batch = 16 if keccak else 256
     mine = list(gdist.proofs_for_rank(a.batch, grp.rank, grp.world))
     rng = np.random.default_rng(1000 + grp.rank)
-    descs = [synth.zkdsa_circuit(3, seed=5, private_key=synth.gl.rand(rng, 4), message=synth.gl.rand(rng, 4)) for _ in mine]
+    if keccak:
+        # BASELINE config 2: one circuit ("build circuit once" [REF src/hash/keccak256.rs:214-231]), one witness per message
+        from plonky2_lib_amd import gadgets
+        msgs = [bytes(rng.integers(0, 256, int(rng.integers(0, 136 * a.keccak_blocks)), dtype=np.uint8)) for _ in mine]
+        descs = [gadgets.keccak256_circuit(m, blocks_num=a.keccak_blocks) for m in msgs]
+        for d in descs:
+            d.hasher, d.circuit_digest = (1 if a.hasher == "keccak" else 0), None
+        a.sub_batch = min(a.sub_batch, 16)
+    else:
+        descs = [synth.zkdsa_circuit(3, seed=5, private_key=synth.gl.rand(rng, 4), message=synth.gl.rand(rng, 4)) for _ in mine]
     nthr = max(1, min(a.threads, len(mine) or 1))
     workers = []
     for t in range(nthr):
@@ -253,8 +269,32 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
     dt = gdist.timed_steps(grp, step, a.steps, 0, device_sync)
     # every proof of the last step is checked by the library's verifier (host code), outside the timed region
     ok = all(bool(w[1].verify(p)) for w in workers if w[5] is not None for p in w[5])
+    if keccak and mine:
+        # the public inputs of every proof are the Keccak-256 digest of its message (GPU Keccak of the product library as the second opinion)
+        want = [workers[0][0].keccak256([m])[0] for m in msgs]
+        got = {}
+        for t, w in enumerate(workers):
+            for i, p in enumerate(w[5] if w[5] is not None else []):
+                got[t + i * nthr] = b"".join(int(v).to_bytes(4, "little") for v in p[-8:])
+        ok = ok and all(got[i] == want[i] for i in range(len(msgs)))
     ok_all = grp.max_over_ranks(0.0 if ok else 1.0) == 0.0
-    if grp.rank == 0:
+    if grp.rank == 0 and keccak:
+        d0 = descs[0]
+        print(json.dumps({
+            "metric": "proofs/sec for the Keccak-256 circuit (BASELINE config 2)",
+            "value": a.batch * a.steps / dt, "unit": "proofs/sec", "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all,
+            "config": {"workload": "%d messages through the reference's Keccak-256 circuit [REF src/hash/keccak256.rs:79-165], %d rate block(s): "
+                                   "2^%d rows x 135 wires (%d gate rows: %s), %s, 8 public inputs = the digest; %s, %d in flight per GPU, "
+                                   "witnesses from host memory" %
+                                   (a.batch, a.keccak_blocks, d0.degree_bits, d0.gadget_rows, ", ".join("%s x%d" % kv for kv in d0.gate_ops.items()),
+                                    "KeccakGoldilocksConfig" if a.hasher == "keccak" else "PoseidonGoldilocksConfig",
+                                    "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
+                       "note": "circuit built by this repository's Python restatement of the gadget (gate placement is not plonky2's); every proof "
+                               "verified by glp_verify and its public inputs compared with the Keccak-256 digest of its message",
+                       "parallelism": "independent proofs sharded over ranks, no collective"}}))
+    elif grp.rank == 0:
         print(json.dumps({
             "metric": "proofs/sec for a batch of independent zkdsa simple-signature proofs (BASELINE config 5)",
             "value": a.batch * a.steps / dt, "unit": "proofs/sec", "n_gpus": grp.world, "steps": a.steps, "warmup": a.warmup,
@@ -295,7 +335,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if a.workload == "zkdsa-batch":
+    if a.workload in ("zkdsa-batch", "keccak256"):
         return zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch)
 
     lg = a.log_n

@@ -1,0 +1,422 @@
+"""Target-level circuit builder and the reference's Keccak-256 circuit, in Python (host side; numpy + integers).
+
+The reference builds its circuits with Rust gadget traits on plonky2's `CircuitBuilder`; neither runs here.  This module
+restates the part needed to obtain a REAL circuit of BASELINE config 2 for the GPU prover instead of a gate-mix stand-in:
+
+  * `GadgetBuilder`: targets with copy constraints (union-find -> sigma cycles), `find_slot`-style packing of operations into
+    gate rows (ArithmeticGate keyed by its two constants), ConstantGate cells, public inputs hashed in-circuit by PoseidonGate
+    rows into the PublicInputGate -- what `CircuitBuilder` + `build()` do, on top of `synth.Builder`;
+  * `CircuitBuilderU32` subset (`mul_add_u32`, `mul_u32`, `add_u32`, `sub_u32`; plonky2_u32, recalled) and the reference's own
+    `CircuitBuilderB32` [REF src/u32/interleaved_u32.rs:56-269]: not / shifts / rotations through U32ArithmeticGate, AND / XOR
+    through the interleaved representation and the reference's three gates [REF src/u32/gates/*.rs];
+  * `hash_keccak256` [REF src/hash/keccak256.rs:79-165] with `add_virtual_hash_input_target` / `public_hash_output`
+    [REF src/hash/types.rs:175-199] and the witness setter `set_keccak256_input_target` [REF src/hash/keccak256.rs:22-37].
+
+Values are computed while building (the builder is handed the input), so one call yields circuit + satisfying witness; the
+structure (gates, constants, sigmas) does not depend on the input, which tests assert.  Gate placement order is this builder's,
+not plonky2's (proof bytes are not comparable with the Rust prover's; the circuit's PUBLIC INPUTS are: the reference's tests pin
+them to the Keccak-256 digests of [REF src/hash/keccak256.rs:196-212,256-277]).
+
+Nothing here touches the GPU or the oracle.
+"""
+import numpy as np
+
+from . import gl_numpy as gl
+from . import synth
+from .synth import (GATE_ARITHMETIC, GATE_CONSTANT, GATE_POSEIDON, GATE_PUBLIC_INPUT, GATE_U32_ARITHMETIC, GATE_U32_INTERLEAVE,
+                    GATE_U32_SUBTRACTION, GATE_UNINTERLEAVE_B32, GATE_UNINTERLEAVE_U32)
+
+P = gl.P
+M32 = (1 << 32) - 1
+
+
+def _interleave(x):
+    """bit i of x -> bit 2i [REF src/u32/gates/interleave_u32.rs:22-45]"""
+    x &= M32
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFF
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FF
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0F
+    x = (x | (x << 2)) & 0x3333333333333333
+    x = (x | (x << 1)) & 0x5555555555555555
+    return x
+
+
+def _deinterleave(v):
+    """bits 0, 2, 4, ... of v packed"""
+    v &= 0x5555555555555555
+    v = (v | (v >> 1)) & 0x3333333333333333
+    v = (v | (v >> 2)) & 0x0F0F0F0F0F0F0F0F
+    v = (v | (v >> 4)) & 0x00FF00FF00FF00FF
+    v = (v | (v >> 8)) & 0x0000FFFF0000FFFF
+    v = (v | (v >> 16)) & 0x00000000FFFFFFFF
+    return v
+
+
+class GadgetBuilder:
+    """Targets are integer ids; `self.val[t]` is the value the witness assigns."""
+
+    def __init__(self, config=None):
+        self.cfg = config or synth.Config.standard_recursion_config()
+        nw, nr = self.cfg.num_wires, self.cfg.num_routed_wires
+        self.val, self._parent, self._cells = [], [], []
+        self.rows = []                 # per row: [gate type, p0, p1, (const0, const1)]
+        self._open = {}                # slot key -> [row, next free op]
+        self._ops = {t: [] for t in (GATE_U32_ARITHMETIC, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_U32,
+                                     GATE_UNINTERLEAVE_B32)}       # advice is filled from these records at build()
+        self._consts = {}
+        self.public_inputs = []
+        self.n_arith = nr // 4
+        self.n_u32a = min(nr // 6, nw // 38)
+        self.n_sub = min(nr // 5, nw // 21)
+        self.n_il = min(nw // 34, nr // 2)
+        self.n_ul = min(nw // 67, nr // 3)
+        self.stats = {}
+
+    # ---- targets and copy constraints
+    def target(self, value):
+        self.val.append(int(value) % P)
+        self._parent.append(len(self.val) - 1)
+        self._cells.append([])
+        return len(self.val) - 1
+
+    def _find(self, t):
+        while self._parent[t] != t:
+            self._parent[t] = self._parent[self._parent[t]]
+            t = self._parent[t]
+        return t
+
+    def connect(self, a, b):
+        if self.val[a] != self.val[b]:
+            raise ValueError("connect() of targets with different values: the witness would violate a copy constraint")
+        ra, rb = self._find(a), self._find(b)
+        if ra != rb:
+            self._parent[rb] = ra
+
+    def _place(self, t, row, col):
+        assert col < self.cfg.num_routed_wires
+        self._cells[t].append((row, col))
+
+    def _wire(self, row, col, value):
+        """a fresh target living in cell (row, col)"""
+        t = self.target(value)
+        self._place(t, row, col)
+        return t
+
+    # ---- rows and slots (CircuitBuilder::find_slot)
+    def _slot(self, key, gate, p0, p1, num_ops, consts=(0, 0)):
+        cur = self._open.get(key)
+        if cur is None or cur[1] == num_ops:
+            self.rows.append([gate, p0, p1, consts])
+            cur = self._open[key] = [len(self.rows) - 1, 0]
+        cur[1] += 1
+        self.stats[gate] = self.stats.get(gate, 0) + 1
+        return cur[0], cur[1] - 1
+
+    def constant(self, c):
+        c = int(c) % P
+        t = self._consts.get(c)
+        if t is None:
+            nc = self.cfg.num_constants
+            row, i = self._slot(("const",), GATE_CONSTANT, nc, 0, nc, consts=None)
+            if self.rows[row][3] is None:
+                self.rows[row][3] = [0] * nc
+            self.rows[row][3][i] = c
+            t = self._consts[c] = self._wire(row, i, c)
+        return t
+
+    def zero(self): return self.constant(0)
+    def one(self): return self.constant(1)
+
+    # ---- ArithmeticGate: c0 x y + c1 z   (gadgets/arithmetic.rs `arithmetic`, without its constant-folding special cases)
+    def arithmetic(self, c0, c1, x, y, z):
+        c0, c1 = int(c0) % P, int(c1) % P
+        row, j = self._slot(("arith", c0, c1), GATE_ARITHMETIC, self.n_arith, 0, self.n_arith, consts=(c0, c1))
+        for k, t in enumerate((x, y, z)):
+            self._place(t, row, 4 * j + k)
+        return self._wire(row, 4 * j + 3, (c0 * self.val[x] * self.val[y] + c1 * self.val[z]) % P)
+
+    def add(self, x, y): return self.arithmetic(1, 1, x, self.one(), y)
+    def sub(self, x, y): return self.arithmetic(1, P - 1, x, self.one(), y)
+    def mul(self, x, y): return self.arithmetic(1, 0, x, y, self.zero())
+
+    def add_many(self, terms):
+        acc = terms[0]
+        for t in terms[1:]:
+            acc = self.add(acc, t)
+        return acc
+
+    def not_(self, b):
+        """BoolTarget negation: 1 - b"""
+        return self.sub(self.one(), b)
+
+    # ---- plonky2_u32 gadgets/arithmetic_u32.rs (recalled): one U32ArithmeticGate / U32SubtractionGate operation each
+    def constant_u32(self, c): return self.constant(c & M32)
+    def zero_u32(self): return self.zero()
+    def one_u32(self): return self.one()
+
+    def mul_add_u32(self, x, y, z):
+        row, i = self._slot(("u32a",), GATE_U32_ARITHMETIC, self.n_u32a, 0, self.n_u32a)
+        for k, t in enumerate((x, y, z)):
+            self._place(t, row, 6 * i + k)
+        prod = self.val[x] * self.val[y] + self.val[z]
+        assert prod < 1 << 64 and max(self.val[x], self.val[y], self.val[z]) <= M32, "u32 operands out of range"
+        self._ops[GATE_U32_ARITHMETIC].append((row, i, prod))
+        return self._wire(row, 6 * i + 3, prod & M32), self._wire(row, 6 * i + 4, prod >> 32)
+
+    def mul_u32(self, x, y): return self.mul_add_u32(x, y, self.zero_u32())
+    def add_u32(self, a, b): return self.mul_add_u32(a, self.one_u32(), b)
+
+    def sub_u32(self, x, y, borrow):
+        row, i = self._slot(("u32s",), GATE_U32_SUBTRACTION, self.n_sub, 0, self.n_sub)
+        for k, t in enumerate((x, y, borrow)):
+            self._place(t, row, 5 * i + k)
+        d = self.val[x] - self.val[y] - self.val[borrow]
+        bo = 1 if d < 0 else 0
+        res = d + (bo << 32)
+        self._ops[GATE_U32_SUBTRACTION].append((row, i, res))
+        return self._wire(row, 5 * i + 3, res), self._wire(row, 5 * i + 4, bo)
+
+    def connect_u32(self, a, b): self.connect(a, b)
+
+    # ---- the reference's CircuitBuilderB32 [REF src/u32/interleaved_u32.rs]
+    def not_u32(self, a):                                   # [REF :59-63]
+        return self.sub_u32(self.constant_u32(0xFFFFFFFF), a, self.zero_u32())[0]
+
+    def lsh_u32(self, a, n): return self.mul_u32(a, self.constant_u32(1 << n))[0]                       # [REF :66-69]
+    def rsh_u32(self, a, n): return a if n == 0 else self.mul_u32(a, self.constant_u32(1 << (32 - n)))[1]    # [REF :72-78]
+
+    def lrot_u32(self, a, n):                               # [REF :81-85]
+        lo, hi = self.mul_u32(a, self.constant_u32(1 << n))
+        return self.add_u32(lo, hi)[0]
+
+    def rrot_u32(self, a, n): return self.lrot_u32(a, 32 - n)
+
+    def interleave_u32(self, x):                            # [REF :93-100]
+        row, op = self._slot(("il",), GATE_U32_INTERLEAVE, self.n_il, 0, self.n_il)
+        self._place(x, row, 2 * op)
+        assert self.val[x] <= M32
+        self._ops[GATE_U32_INTERLEAVE].append((row, op, self.val[x]))
+        return self._wire(row, 2 * op + 1, _interleave(self.val[x]))
+
+    def _uninterleave(self, gate, key, x_dirty):
+        row, op = self._slot((key,), gate, self.n_ul, 0, self.n_ul)
+        self._place(x_dirty, row, 3 * op)
+        v = self.val[x_dirty]                                # < 2^64 by construction; as a field element it is < p
+        self._ops[gate].append((row, op, v))
+        ev, od = _deinterleave(v >> 1), _deinterleave(v)     # big-endian bit pairs: "evens" = the high bit of each pair
+        if gate == GATE_UNINTERLEAVE_B32:
+            ev, od = _interleave(ev), _interleave(od)
+        return self._wire(row, 3 * op + 1, ev), self._wire(row, 3 * op + 2, od)
+
+    def uninterleave_to_u32(self, x): return self._uninterleave(GATE_UNINTERLEAVE_U32, "ul32", x)      # [REF :102-116]
+    def uninterleave_to_b32(self, x): return self._uninterleave(GATE_UNINTERLEAVE_B32, "ulb32", x)     # [REF :118-132]
+
+    def and_xor_b32(self, x, y): return self.uninterleave_to_b32(self.add(x, y))                        # [REF :183-186]
+    def and_xor_b32_to_u32(self, x, y): return self.uninterleave_to_u32(self.add(x, y))                 # [REF :194-197]
+    def and_xor_u32_to_u32(self, x, y): return self.and_xor_b32_to_u32(self.interleave_u32(x), self.interleave_u32(y))
+    def and_u32(self, x, y): return self.and_xor_u32_to_u32(x, y)[0]
+    def xor_u32(self, x, y): return self.and_xor_u32_to_u32(x, y)[1]
+
+    def unsafe_xor_many_u32(self, x):                       # [REF :148-181], same case split
+        n = len(x)
+        if n == 0: return self.zero_u32()
+        if n == 1: return x[0]
+        if n == 2: return self.xor_u32(x[0], x[1])
+        if n == 3: return self.xor_u32(self.xor_u32(x[0], x[1]), x[2])
+        r = self.interleave_u32(x[0])
+        for i in range((n - 3) // 2):
+            a, b = self.interleave_u32(x[1 + 2 * i]), self.interleave_u32(x[2 + 2 * i])
+            r = self.uninterleave_to_b32(self.add_many([r, a, b]))[1]
+        if n % 2 == 0:
+            r = self.and_xor_b32(r, self.interleave_u32(x[n - 3]))[1]
+        a, b = self.interleave_u32(x[n - 2]), self.interleave_u32(x[n - 1])
+        return self.uninterleave_to_u32(self.add_many([r, a, b]))[1]
+
+    def lrot_u64(self, a, n):                               # [REF :213-220]
+        lo, hi = (a[0], a[1]) if n < 32 else (a[1], a[0])
+        p2 = self.constant_u32(1 << (n % 32))
+        lo0, hi0 = self.mul_u32(lo, p2)
+        lo1, hi1 = self.mul_add_u32(hi, p2, hi0)
+        return [self.add_u32(lo0, hi1)[0], lo1]
+
+    def unsafe_xor_many_u64(self, xs): return [self.unsafe_xor_many_u32([e[0] for e in xs]), self.unsafe_xor_many_u32([e[1] for e in xs])]
+    def xor_u64(self, x, y): return [self.xor_u32(x[0], y[0]), self.xor_u32(x[1], y[1])]
+    def and_u64(self, x, y): return [self.and_u32(x[0], y[0]), self.and_u32(x[1], y[1])]
+    def not_u64(self, x): return [self.not_u32(x[0]), self.not_u32(x[1])]
+
+    def conditional_u32(self, x, y, z):                     # z ? x : y   [REF :248-252]
+        not_z = self.not_(z)
+        maybe_x = self.mul_u32(x, z)[0]
+        return self.mul_add_u32(y, not_z, maybe_x)[0]
+
+    def conditional_u64(self, x, y, z): return [self.conditional_u32(x[0], y[0], z), self.conditional_u32(x[1], y[1], z)]
+
+    def register_public_input(self, t): self.public_inputs.append(t)
+
+    # ---- build(): rows -> synth.Builder (selectors, sigmas) + the witness
+    def build(self, min_log_n=0):
+        from . import poseidon_py as pp
+        cfg = self.cfg
+        # public-input hash in circuit: hash_n_to_hash_no_pad over the public inputs, PoseidonGate rows (rate 8, overwrite
+        # mode), result copy-constrained into the PublicInputGate's four wires [UPSTREAM plonk/circuit_builder.rs build()]
+        pis = list(self.public_inputs)
+        zero = self.zero()
+        self.rows.append([GATE_PUBLIC_INPUT, 0, 0, (0, 0)])
+        row_pi = len(self.rows) - 1
+        state_t, state_v = [zero] * 12, [0] * 12
+        poseidon_rows = []
+        for off in range(0, len(pis), 8):
+            chunk = pis[off:off + 8]
+            for k, t in enumerate(chunk):
+                state_t[k], state_v[k] = t, self.val[t]
+            self.rows.append([GATE_POSEIDON, 0, 0, (0, 0)])
+            row = len(self.rows) - 1
+            for k in range(12):
+                self._place(state_t[k], row, k)
+            self._place(zero, row, 24)                       # swap flag
+            out = pp.permute_trace(state_v)[0]
+            poseidon_rows.append((row, list(state_v)))
+            state_t = [self._wire(row, 12 + k, out[k]) for k in range(12)]
+            state_v = list(out)
+        pi_hash = state_v[:4] if pis else [0, 0, 0, 0]
+        for k in range(4):
+            self._place(state_t[k] if pis else zero, row_pi, k)
+        nrows = len(self.rows)
+        log_n = max(min_log_n, 2, (nrows - 1).bit_length())
+        b = synth.Builder(cfg, log_n, seed=0)
+        used = np.arange(nrows)
+        b.wires[:, used] = 0
+        by_kind = {}
+        for r, (g, p0, p1, consts) in enumerate(self.rows):
+            by_kind.setdefault((g, p0, p1), []).append(r)
+            if consts is not None:
+                for k, c in enumerate(consts):
+                    b.gate_consts[k, r] = c
+        for (g, p0, p1), rr in by_kind.items():
+            b.set_rows(np.array(rr), g, p0, p1)
+        # routed cells of every target; one sigma cycle per connected class
+        classes = {}
+        for t in range(len(self.val)):
+            if self._cells[t]:
+                classes.setdefault(self._find(t), []).extend(self._cells[t])
+            for (r, c) in self._cells[t]:
+                b.wires[c, r] = self.val[t]
+        for cells in classes.values():
+            if len(cells) > 1:
+                assert len(set(cells)) == len(cells)
+                b.connect_cycle([r for r, _ in cells], [c for _, c in cells])
+        # advice wires (what the gates' row-local generators produce), vectorised per gate type
+        w = b.wires
+
+        def recs(gate):
+            a = self._ops[gate]
+            if not a:
+                return None
+            return (np.array([x[0] for x in a]), np.array([x[1] for x in a]), np.array([x[2] for x in a], dtype=np.uint64))
+        # every U32ArithmeticGate slot (used or not) needs inverse = 1 / (2^32 - 1 - output_high)
+        inv_free = pow(M32, P - 2, P)
+        for r, (g, p0, p1, _) in enumerate(self.rows):
+            if g == GATE_U32_ARITHMETIC:
+                for i in range(p0):
+                    w[6 * i + 5, r] = inv_free
+        rc = recs(GATE_U32_ARITHMETIC)
+        if rc is not None:
+            rr, ii, prod = rc
+            hi = prod >> np.uint64(32)
+            w[6 * ii + 5, rr] = [pow((M32 - int(h)) % P, P - 2, P) for h in hi]
+            for k in range(32):
+                w[6 * self.n_u32a + 32 * ii + k, rr] = (prod >> np.uint64(2 * k)) & np.uint64(3)
+        rc = recs(GATE_U32_SUBTRACTION)
+        if rc is not None:
+            rr, ii, res = rc
+            for k in range(16):
+                w[5 * self.n_sub + 16 * ii + k, rr] = (res >> np.uint64(2 * k)) & np.uint64(3)
+        rc = recs(GATE_U32_INTERLEAVE)
+        if rc is not None:
+            rr, ii, x = rc
+            for k in range(32):                              # big-endian bits
+                w[2 * self.n_il + 32 * ii + k, rr] = (x >> np.uint64(31 - k)) & np.uint64(1)
+        for gate in (GATE_UNINTERLEAVE_U32, GATE_UNINTERLEAVE_B32):
+            rc = recs(gate)
+            if rc is not None:
+                rr, ii, v = rc
+                for k in range(64):
+                    w[3 * self.n_ul + 64 * ii + k, rr] = (v >> np.uint64(63 - k)) & np.uint64(1)
+        for row, inputs in poseidon_rows:
+            synth._fill_poseidon_row(b, row, inputs)
+        b.public_inputs = np.array([self.val[t] for t in pis], dtype=np.uint64)
+        c = b.build()
+        c.pi_hash = np.array(pi_hash, dtype=np.uint64)
+        c.gadget_rows = nrows
+        c.gate_ops = {synth._GATE_META[g][1].split(" ")[0].split("(")[0]: n for g, n in sorted(self.stats.items())}
+        return c
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Keccak-256 [REF src/hash/keccak256.rs]
+KECCAK256_R = 1088
+KECCAKF_ROTC = [1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44]
+KECCAKF_PILN = [10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1]
+KECCAKF_RNDC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B, 0x0000000080000001,
+                0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+                0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+                0x000000000000800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+
+
+def keccak_f1600(gb, s):
+    """`_hash_keccak256_f1600` [REF src/hash/keccak256.rs:79-128]; s: 25 lanes of [lo, hi] U32 targets, updated in place."""
+    rndc = [[gb.constant_u32(c & M32), gb.constant_u32(c >> 32)] for c in KECCAKF_RNDC]
+    for rnd in range(24):
+        bc = [gb.unsafe_xor_many_u64([s[i], s[i + 5], s[i + 10], s[i + 15], s[i + 20]]) for i in range(5)]       # theta
+        for i in range(5):
+            t2 = gb.xor_u64(bc[(i + 4) % 5], gb.lrot_u64(bc[(i + 1) % 5], 1))
+            for j in range(5):
+                s[5 * j + i] = gb.xor_u64(s[5 * j + i], t2)
+        t = s[1]                                                                                                  # rho, pi
+        for i in range(24):
+            j = KECCAKF_PILN[i]
+            s[j], t = gb.lrot_u64(t, KECCAKF_ROTC[i]), s[j]
+        for j in range(5):                                                                                        # chi
+            bc = [s[5 * j + i] for i in range(5)]
+            for i in range(5):
+                t2 = gb.and_u64(bc[(i + 2) % 5], gb.not_u64(bc[(i + 1) % 5]))
+                s[5 * j + i] = gb.xor_u64(s[5 * j + i], t2)
+        s[0] = gb.xor_u64(s[0], rndc[rnd])                                                                        # iota
+
+
+def keccak256_circuit(message, blocks_num=1, config=None, min_log_n=0):
+    """The circuit of `test_keccak256_short` / `_long` [REF src/hash/keccak256.rs:214-231,279-295]:
+    `add_virtual_hash_input_target(blocks_num, KECCAK256_R)`, `hash_keccak256`, `public_hash_output`, with the witness
+    `set_keccak256_input_target(message)` [REF :22-37].  Returns a synth.Circuit whose 8 public inputs are the little-endian u32
+    limbs of keccak256(message) as the circuit computed them.  `c.hasher` is left at 0 (PoseidonGoldilocksConfig); the long
+    test of the reference sets KeccakGoldilocksConfig (`c.hasher = 1`)."""
+    message = bytes(message)
+    num_actual = 1 + (8 * len(message)) // KECCAK256_R
+    if num_actual > blocks_num:
+        raise ValueError("message needs %d blocks, the circuit has %d" % (num_actual, blocks_num))
+    padded = bytearray(blocks_num * (KECCAK256_R // 8))
+    padded[:len(message)] = message
+    padded[len(message)] |= 0x01                              # bit right after the end of the message
+    padded[num_actual * (KECCAK256_R // 8) - 1] |= 0x80       # last bit of the last block
+    gb = GadgetBuilder(config)
+    limbs = [gb.target(int.from_bytes(padded[4 * i:4 * i + 4], "little")) for i in range(len(padded) // 4)]
+    blocks = [gb.target(1 if i < num_actual - 1 else 0) for i in range(blocks_num - 1)]      # add_virtual_bool_target_unsafe
+    chunks = KECCAK256_R // 64
+    zero = gb.zero_u32()
+    state = [[zero, zero] for _ in range(25)]
+    for i in range(chunks):
+        state[i] = [limbs[2 * i], limbs[2 * i + 1]]
+    keccak_f1600(gb, state)
+    for k, blk in enumerate(blocks):
+        start = (k + 1) * chunks * 2
+        nxt = [[gb.xor_u32(s[0], limbs[start + 2 * i]), gb.xor_u32(s[1], limbs[start + 2 * i + 1])] if i < chunks else list(s)
+               for i, s in enumerate(state)]
+        keccak_f1600(gb, nxt)
+        state = [gb.conditional_u64(nxt[i], state[i], blk) for i in range(25)]
+    out = [gb.target(gb.val[state[i // 2][i % 2]]) for i in range(8)]       # add_virtual_biguint_target(8)
+    for i in range(8):
+        gb.connect_u32(state[i // 2][i % 2], out[i])
+        gb.register_public_input(out[i])
+    c = gb.build(min_log_n)
+    c.digest_bytes = b"".join(int(v).to_bytes(4, "little") for v in c.public_inputs)
+    return c

@@ -44,6 +44,13 @@ def test_zkdsa_batch_workload_line():
     assert d["verified"] is True and d["value"] > 0 and "glp_prove_batch" in d["config"]["workload"]
 
 
+def test_keccak256_workload_line():
+    """BASELINE config 2 through bench.py: the real Keccak-256 circuit, every proof verified and its public inputs = the digest."""
+    d = _run(["--workload", "keccak256", "--batch", "4", "--steps", "1", "--warmup", "1", "--hasher", "keccak"])
+    assert d["verified"] is True and d["value"] > 0 and "KeccakGoldilocksConfig" in d["config"]["workload"]
+    assert "2^13 rows" in d["config"]["workload"]
+
+
 def test_c99_consumer_proves_the_sample_circuit_file(tmp_path):
     """A plain C program against include/glp.h (csrc/examples/abi_smoke.c): reads tests/golden/zkdsa_2_3.glpc, creates the circuit,
     proves the file's witness and verifies the proof -- the path a Rust / Go host takes, without Python in between."""

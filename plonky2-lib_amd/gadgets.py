@@ -64,6 +64,7 @@ class GadgetBuilder:
         self._ops = {t: [] for t in (GATE_U32_ARITHMETIC, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_U32,
                                      GATE_UNINTERLEAVE_B32)}       # advice is filled from these records at build()
         self._consts = {}
+        self._poseidon_rows = []       # (row, 12 input values): S-box traces are filled at build()
         self.public_inputs = []
         self.n_arith = nr // 4
         self.n_u32a = min(nr // 6, nw // 38)
@@ -253,6 +254,77 @@ class GadgetBuilder:
 
     def register_public_input(self, t): self.public_inputs.append(t)
 
+    # ---- plonky2 gadgets the SMT circuits use (recalled; semantics, not gate placement, is what matters here)
+    def mul_add(self, x, y, z): return self.arithmetic(1, 1, x, y, z)
+    def mul_sub(self, x, y, z): return self.arithmetic(1, P - 1, x, y, z)
+    def mul_const_add(self, c, x, y): return self.arithmetic(c, 1, self.one(), x, y)
+    def and_(self, a, b): return self.mul(a, b)
+    def constant_bool(self, b): return self.one() if b else self.zero()
+    def assert_zero(self, t): self.connect(t, self.zero())
+
+    def assert_bool(self, b):                                # b (b - 1) = 0
+        self.assert_zero(self.mul_sub(b, b, b))
+
+    def add_virtual_bool_target_safe(self, value):
+        b = self.target(1 if value else 0)
+        self.assert_bool(b)
+        return b
+
+    def is_equal(self, x, y):
+        """gadgets/arithmetic.rs `is_equal` with its EqualityGenerator: equal = (x == y), inv = 1 / (x - y) or 0"""
+        d = (self.val[x] - self.val[y]) % P
+        equal = self.target(1 if d == 0 else 0)
+        not_equal = self.not_(equal)
+        inv = self.target(pow(d, P - 2, P) if d else 0)
+        diff = self.sub(x, y)
+        self.assert_zero(self.mul(diff, equal))
+        self.assert_zero(self.sub(self.mul(diff, inv), not_equal))
+        return equal
+
+    def permute(self, state):
+        """One PoseidonGate row (`PoseidonHash::permute_swapped` with swap = false): 12 input targets -> 12 output targets."""
+        from . import poseidon_py as pp
+        self.rows.append([GATE_POSEIDON, 0, 0, (0, 0)])
+        row = len(self.rows) - 1
+        self.stats[GATE_POSEIDON] = self.stats.get(GATE_POSEIDON, 0) + 1
+        vals = [self.val[t] for t in state]
+        for k in range(12):
+            self._place(state[k], row, k)
+        self._place(self.zero(), row, 24)                    # swap flag
+        self._poseidon_rows.append((row, vals))
+        out = pp.permute_trace(vals)[0]
+        return [self._wire(row, 12 + k, out[k]) for k in range(12)]
+
+    def hash_n_to_hash_no_pad(self, inputs):
+        """hashing.rs `hash_n_to_m_no_pad` in circuit: rate 8, overwrite mode, no padding; no input -> the zero state's first four."""
+        state = [self.zero()] * 12
+        for off in range(0, len(inputs), 8):
+            chunk = inputs[off:off + 8]
+            state = list(chunk) + state[len(chunk):]
+            state = self.permute(state)
+        return state[:4]
+
+    def split_le(self, x, num_bits):
+        """gadgets/split_base.rs `split_le`: BaseSumGate<2> rows of 63 limbs, surplus limbs tied to zero, the weighted sum tied to x."""
+        nl = min(63, self.cfg.num_routed_wires - 1)
+        k = -(-num_bits // nl)
+        v = self.val[x]
+        bits, sums = [], []
+        for g in range(k):
+            self.rows.append([synth.GATE_BASE_SUM, nl, 2, (0, 0)])
+            row = len(self.rows) - 1
+            self.stats[synth.GATE_BASE_SUM] = self.stats.get(synth.GATE_BASE_SUM, 0) + 1
+            part = (v >> (nl * g)) & ((1 << nl) - 1)
+            sums.append(self._wire(row, 0, part))
+            bits += [self._wire(row, 1 + i, (part >> i) & 1) for i in range(nl)]
+        for b in bits[num_bits:]:
+            self.assert_zero(b)
+        acc = self.zero()
+        for t in reversed(sums):
+            acc = self.mul_const_add(1 << nl, acc, t)
+        self.connect(acc, x)
+        return bits[:num_bits]
+
     # ---- build(): rows -> synth.Builder (selectors, sigmas) + the witness
     def build(self, min_log_n=0):
         from . import poseidon_py as pp
@@ -261,26 +333,13 @@ class GadgetBuilder:
         # mode), result copy-constrained into the PublicInputGate's four wires [UPSTREAM plonk/circuit_builder.rs build()]
         pis = list(self.public_inputs)
         zero = self.zero()
+        digest = self.hash_n_to_hash_no_pad(pis) if pis else [zero] * 4
         self.rows.append([GATE_PUBLIC_INPUT, 0, 0, (0, 0)])
         row_pi = len(self.rows) - 1
-        state_t, state_v = [zero] * 12, [0] * 12
-        poseidon_rows = []
-        for off in range(0, len(pis), 8):
-            chunk = pis[off:off + 8]
-            for k, t in enumerate(chunk):
-                state_t[k], state_v[k] = t, self.val[t]
-            self.rows.append([GATE_POSEIDON, 0, 0, (0, 0)])
-            row = len(self.rows) - 1
-            for k in range(12):
-                self._place(state_t[k], row, k)
-            self._place(zero, row, 24)                       # swap flag
-            out = pp.permute_trace(state_v)[0]
-            poseidon_rows.append((row, list(state_v)))
-            state_t = [self._wire(row, 12 + k, out[k]) for k in range(12)]
-            state_v = list(out)
-        pi_hash = state_v[:4] if pis else [0, 0, 0, 0]
         for k in range(4):
-            self._place(state_t[k] if pis else zero, row_pi, k)
+            self._place(digest[k], row_pi, k)
+        pi_hash = [self.val[t] for t in digest]
+        poseidon_rows = self._poseidon_rows
         nrows = len(self.rows)
         log_n = max(min_log_n, 2, (nrows - 1).bit_length())
         b = synth.Builder(cfg, log_n, seed=0)
@@ -419,4 +478,201 @@ def keccak256_circuit(message, blocks_num=1, config=None, min_log_n=0):
         gb.register_public_input(out[i])
     c = gb.build(min_log_n)
     c.digest_bytes = b"".join(int(v).to_bytes(4, "little") for v in c.public_inputs)
+    return c
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Sparse Merkle tree inclusion proof (BASELINE config 4) [REF src/smt/gadgets/verify/verify_smt.rs, src/smt/gadgets/common.rs]
+def _poseidon_hash_no_pad(values):
+    from . import poseidon_py as pp
+    state = [0] * 12
+    for off in range(0, len(values), 8):
+        chunk = [int(v) % P for v in values[off:off + 8]]
+        state = chunk + state[len(chunk):]
+        state = pp.permute_trace(state)[0]
+    return tuple(state[:4])
+
+
+ZERO_HASH = (0, 0, 0, 0)
+
+
+def hash_out_from_u128(v):
+    """`GoldilocksHashOut::from_u128` [REF src/smt/goldilocks_poseidon/hash/mod.rs:254-267]: four little-endian u32 limbs"""
+    return tuple((v >> (32 * i)) & M32 for i in range(4))
+
+
+def _key_bits(key):
+    """`KeyLike::to_bits` [REF src/smt/goldilocks_poseidon/mod.rs:27-48]: little-endian bits of the four elements' 8 bytes each"""
+    return [(key[i // 64] >> (i % 64)) & 1 for i in range(256)]
+
+
+class SparseMerkleTree:
+    """The native tree the reference takes its witnesses from (`PoseidonSparseMerkleTreeMemory`), restated: `insert` / `find`
+    [REF src/smt/tree.rs:253-372,589-676] with `PoseidonNodeHash` [REF src/smt/goldilocks_poseidon/mod.rs:160-184]:
+    internal = two_to_one(left, right); leaf = hash_pad([key, value, 1]) = the un-padded hash of [key, value, 1, 1, 0, 1]."""
+
+    def __init__(self):
+        self.nodes, self.root = {}, ZERO_HASH
+
+    @staticmethod
+    def leaf_hash(key, value): return _poseidon_hash_no_pad(list(key) + list(value) + [1, 1, 0, 1])
+    @staticmethod
+    def internal_hash(left, right): return _poseidon_hash_no_pad(list(left) + list(right))
+
+    def _put(self, node):
+        h = self.leaf_hash(*node[1:]) if node[0] == "leaf" else self.internal_hash(*node[1:])
+        self.nodes[h] = node
+        return h
+
+    def insert(self, key, value):
+        if tuple(value) == ZERO_HASH:
+            raise ValueError("value must be non-zero")
+        bits = _key_bits(key)
+
+        def ins(h, level):
+            if h == ZERO_HASH:
+                return self._put(("leaf", tuple(key), tuple(value)))
+            node = self.nodes[h]
+            if node[0] == "leaf":
+                if node[1] == tuple(key):
+                    raise ValueError("given key already exists")
+                old_bits = _key_bits(node[1])
+                lvl = level
+                while old_bits[lvl] == bits[lvl]:            # both leaves move down while their paths agree
+                    lvl += 1
+                new = self._put(("leaf", tuple(key), tuple(value)))
+                cur = self._put(("int", h, new) if bits[lvl] else ("int", new, h))
+                for l in range(lvl - 1, level - 1, -1):
+                    cur = self._put(("int", ZERO_HASH, cur) if bits[l] else ("int", cur, ZERO_HASH))
+                return cur
+            left, right = node[1], node[2]
+            return self._put(("int", left, ins(right, level + 1)) if bits[level] else ("int", ins(left, level + 1), right))
+        self.root = ins(self.root, 0)
+
+    def find(self, key):
+        """-> dict(root, found, siblings (root downwards), key, value, not_found_key, not_found_value, is_old0)"""
+        bits, h, sib = _key_bits(key), self.root, []
+        level = 0
+        while True:
+            if h == ZERO_HASH:
+                return dict(root=self.root, found=False, siblings=sib, key=tuple(key), value=ZERO_HASH, not_found_key=ZERO_HASH,
+                            not_found_value=ZERO_HASH, is_old0=True)
+            node = self.nodes[h]
+            if node[0] == "leaf":
+                hit = node[1] == tuple(key)
+                return dict(root=self.root, found=hit, siblings=sib, key=tuple(key), value=node[2] if hit else ZERO_HASH,
+                            not_found_key=ZERO_HASH if hit else node[1], not_found_value=ZERO_HASH if hit else node[2], is_old0=False)
+            sib.append(node[1] if bits[level] else node[2])
+            h = node[2] if bits[level] else node[1]
+            level += 1
+
+
+def _logical_and_not(gb, x, y): return gb.arithmetic(P - 1, 1, x, y, x)                     # x (1 - y)  [REF src/smt/gadgets/common.rs:211-222]
+
+
+def _conditionally_reverse(gb, x, y, cond):                                                    # [REF src/smt/gadgets/common.rs:128-156]
+    left, right = [], []
+    for xi, yi in zip(x, y):
+        d = gb.sub(yi, xi)
+        left.append(gb.arithmetic(1, 1, d, cond, xi))
+        right.append(gb.arithmetic(P - 1, 1, d, cond, yi))
+    return left, right
+
+
+def _is_equal_hash_out(gb, l, r):                                                              # [REF src/smt/gadgets/common.rs:318-330]
+    out = gb.constant_bool(True)
+    for a, b in zip(l, r):
+        out = gb.and_(out, gb.is_equal(a, b))
+    return out
+
+
+def _calc_leaf_hash(gb, key, value):                                                           # [REF src/smt/gadgets/common.rs:87-101]
+    one, zero = gb.one(), gb.zero()
+    return gb.hash_n_to_hash_no_pad(list(key) + list(value) + [one, one, zero, one])
+
+
+def _calc_internal_hash(gb, child, sibling, swap):                                             # [REF src/smt/gadgets/common.rs:103-113,11-25]
+    left, right = _conditionally_reverse(gb, child, sibling, swap)
+    return gb.hash_n_to_hash_no_pad(left + right)
+
+
+def _smt_lev_ins(gb, enabled, siblings):                                                       # [REF src/smt/gadgets/common.rs:372-431]
+    n = len(siblings)
+    zero4 = [gb.zero()] * 4
+    is_zeros = [_is_equal_hash_out(gb, s, zero4) for s in siblings][::-1]
+    gb.assert_zero(_logical_and_not(gb, enabled, is_zeros[0]))      # the last level's sibling must be zero
+    lev_ins = [gb.not_(is_zeros[1])]
+    done = [lev_ins[0]]
+    for i in range(1, n - 1):
+        lev_ins.append(_logical_and_not(gb, gb.not_(is_zeros[i + 1]), done[-1]))
+        done.append(gb.add(lev_ins[-1], done[-1]))
+    lev_ins.append(gb.not_(done[-1]))
+    return lev_ins[::-1]
+
+
+def _smt_verifier_sm(gb, is0, lev_ins, fnc, prev):                                             # [REF src/smt/gadgets/verify/verify_smt.rs:160-212]
+    aux1 = gb.mul(prev["top"], lev_ins)
+    aux2 = gb.mul(aux1, fnc)
+    top = gb.sub(prev["top"], aux1)
+    i_new = gb.sub(aux1, aux2)
+    i_old = gb.mul(aux2, gb.sub(gb.constant_bool(True), is0))
+    i0 = gb.mul(aux1, is0)
+    na = gb.add(gb.add(gb.add(prev["na"], prev["i_new"]), prev["i_old"]), prev["i0"])
+    return dict(top=top, i_new=i_new, i_old=i_old, i0=i0, na=na)
+
+
+def _smt_verifier_level(gb, st, sibling, old1_leaf, new1_leaf, lr_bit, child):                 # [REF src/smt/gadgets/verify/verify_smt.rs:109-158]
+    h = _calc_internal_hash(gb, child, sibling, lr_bit)
+    out = []
+    for a, b, c in zip(h, old1_leaf, new1_leaf):
+        r = gb.add(gb.mul(a, st["top"]), gb.mul(b, st["i_old"]))
+        out.append(gb.add(r, gb.mul(c, st["i_new"])))
+    return out
+
+
+def smt_inclusion_circuit(tree, key, n_levels=16, enabled=True, config=None, public=False, min_log_n=0):
+    """`SparseMerkleInclusionProofTarget::add_virtual_to(builder, n_levels)` + `set_witness(tree.find(key), enabled)`
+    [REF src/smt/gadgets/verify/verify_smt.rs:41-97,214-307; the driver is src/smt/gadgets/verify/mod.rs:3-52].  `public`: also
+    register root, key and value as public inputs (the reference's driver registers none)."""
+    w = tree.find(key)
+    if len(w["siblings"]) >= n_levels:
+        raise ValueError("the proof has %d siblings, the circuit %d levels" % (len(w["siblings"]), n_levels))
+    gb = GadgetBuilder(config)
+    h4 = lambda v: [gb.target(x) for x in v]
+    siblings = [h4(s) for s in w["siblings"]] + [h4(ZERO_HASH) for _ in range(n_levels - len(w["siblings"]))]
+    root, old_key, old_value = h4(w["root"]), h4(w["not_found_key"]), h4(w["not_found_value"])
+    key_t, value_t = h4(w["key"]), h4(w["value"])
+    enabled_t = gb.add_virtual_bool_target_safe(enabled)
+    is_old0 = gb.add_virtual_bool_target_safe(w["is_old0"])
+    fnc = gb.add_virtual_bool_target_safe(not w["found"])
+    # verify_smt_inclusion_proof
+    true_t, false_t = gb.constant_bool(True), gb.constant_bool(False)
+    hash1_old = _calc_leaf_hash(gb, old_key, old_value)
+    hash1_new = _calc_leaf_hash(gb, key_t, value_t)
+    n2b_new = [b for i in range(4) for b in gb.split_le(key_t[i], 64)]
+    lev_ins = _smt_lev_ins(gb, enabled_t, siblings)
+    st = dict(top=enabled_t, i0=false_t, i_old=false_t, i_new=false_t, na=gb.sub(true_t, enabled_t))
+    sm = []
+    for i in range(n_levels):
+        st = _smt_verifier_sm(gb, is_old0, lev_ins[i], fnc, st)
+        sm.append(st)
+    flag = gb.add(gb.add(gb.add(sm[-1]["na"], sm[-1]["i_old"]), sm[-1]["i_new"]), sm[-1]["i0"])
+    gb.connect(flag, true_t)
+    sm.reverse()
+    levels = []
+    for i in range(n_levels):
+        child = [gb.zero()] * 4 if i == 0 else levels[i - 1]
+        levels.append(_smt_verifier_level(gb, sm[i], siblings[n_levels - 1 - i], hash1_old, hash1_new, n2b_new[n_levels - 1 - i], child))
+    levels.reverse()
+    are_keys_equal = _is_equal_hash_out(gb, old_key, key_t)
+    keys_ok = gb.and_(gb.and_(_logical_and_not(gb, fnc, is_old0), enabled_t), are_keys_equal)
+    gb.connect(keys_ok, false_t)
+    # enforce_equal_if_enabled(root, levels[0], enabled)   [REF src/smt/gadgets/common.rs:347-357]
+    gb.connect(_logical_and_not(gb, enabled_t, _is_equal_hash_out(gb, root, levels[0])), false_t)
+    if public:
+        for t in root + key_t + value_t:
+            gb.register_public_input(t)
+    c = gb.build(min_log_n)
+    c.smt_witness = w
+    c.computed_root = tuple(gb.val[t] for t in levels[0])
     return c

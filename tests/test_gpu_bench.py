@@ -51,6 +51,12 @@ def test_keccak256_workload_line():
     assert "2^13 rows" in d["config"]["workload"]
 
 
+def test_smt_workload_line():
+    """BASELINE config 4 through bench.py: the real 16-level inclusion circuit, every proof verified and bound to the tree's root."""
+    d = _run(["--workload", "smt", "--batch", "32", "--sub-batch", "16", "--steps", "1", "--warmup", "1"])
+    assert d["verified"] is True and d["value"] > 0 and "PoseidonGate x22" in d["config"]["workload"]      # 20 of the gadget + 2 for the 12 public inputs' hash
+
+
 def test_c99_consumer_proves_the_sample_circuit_file(tmp_path):
     """A plain C program against include/glp.h (csrc/examples/abi_smoke.c): reads tests/golden/zkdsa_2_3.glpc, creates the circuit,
     proves the file's witness and verifies the proof -- the path a Rust / Go host takes, without Python in between."""

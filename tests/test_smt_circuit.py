@@ -1,0 +1,128 @@
+"""The reference's sparse-Merkle-tree inclusion circuit (BASELINE config 4) rebuilt gadget for gadget in plonky2-lib_amd/gadgets.py:
+`SparseMerkleInclusionProofTarget::add_virtual_to` + `verify_smt_inclusion_proof` [REF src/smt/gadgets/verify/verify_smt.rs:41-307,
+src/smt/gadgets/common.rs], with the native tree that supplies its witness [REF src/smt/tree.rs, src/smt/goldilocks_poseidon/mod.rs].
+CPU half: the scenario of the reference's own driver [REF src/smt/gadgets/verify/mod.rs:3-52] and of `test_calc_node_hash`
+[REF src/smt/gadgets/common.rs:27-85]; the checker proves and verifies the circuits."""
+import numpy as np
+import pytest
+
+from plonky2_lib_amd import gadgets as G
+import plonky2_lib_amd.synth as synth
+
+H = G.hash_out_from_u128
+
+
+def reference_tree():
+    """keys 1, 12, 5 -> values 2, 1, 51 [REF src/smt/gadgets/verify/mod.rs:24-35]"""
+    t = G.SparseMerkleTree()
+    for k, v in ((1, 2), (12, 1), (5, 51)):
+        t.insert(H(k), H(v))
+    return t
+
+
+def test_native_hashes_follow_the_pinned_relations(oracle):
+    """Leaf = `hash_pad([key, value, 1])` [REF src/smt/goldilocks_poseidon/mod.rs:170-180] = un-padded hash of [key, value, 1, 1, 0, 1]
+    [REF src/smt/gadgets/common.rs:87-101]; internal = two_to_one."""
+    k, v = H(1), H(2)
+    assert G.SparseMerkleTree.leaf_hash(k, v) == tuple(int(x) for x in oracle.hash_pad(list(k) + list(v) + [1]))
+    assert G.SparseMerkleTree.internal_hash(k, v) == tuple(int(x) for x in oracle.two_to_one(np.array(k, np.uint64), np.array(v, np.uint64)))
+    assert G.SparseMerkleTree.internal_hash(G.ZERO_HASH, G.ZERO_HASH) == (4330397376401421145, 14124799381142128323, 8742572140681234676,
+                                                                          14345658006221440202)     # [REF src/zkdsa/circuits/mod.rs:85-101]
+
+
+def test_tree_find_and_insert():
+    t = reference_tree()
+    w = t.find(H(5))
+    assert w["found"] and w["value"] == H(51) and not w["is_old0"] and 0 < len(w["siblings"]) < 16
+    # keys 1 and 5 share their low two bits (01): the leaf of key 5 sits below two internal nodes on that side
+    assert len(w["siblings"]) == 3
+    # recompute the root from the proof, bottom up
+    cur = t.leaf_hash(H(5), H(51))
+    bits = G._key_bits(H(5))
+    for lvl in range(len(w["siblings"]) - 1, -1, -1):
+        cur = t.internal_hash(w["siblings"][lvl], cur) if bits[lvl] else t.internal_hash(cur, w["siblings"][lvl])
+    assert cur == t.root
+    miss = t.find(H(7))                                      # 7 = ..0111: ends at the leaf of another key or at an empty branch
+    assert not miss["found"]
+    with pytest.raises(ValueError):
+        t.insert(H(5), H(9))
+    with pytest.raises(ValueError):
+        t.insert(H(99), G.ZERO_HASH)
+    # insertion order does not change the root
+    t2 = G.SparseMerkleTree()
+    for k, v in ((5, 51), (1, 2), (12, 1)):
+        t2.insert(H(k), H(v))
+    assert t2.root == t.root
+    assert G.SparseMerkleTree().find(H(1))["is_old0"]
+
+
+def test_inclusion_circuit_shape_and_root():
+    t = reference_tree()
+    c = G.smt_inclusion_circuit(t, H(5))
+    assert c.computed_root == t.root                          # the root the gates computed from leaf, siblings and key bits
+    # SURVEY.md section 8 row Q, cfg 4: 2 leaf hashes x 2 permutations + 16 internal = 20 PoseidonGate rows; split_le(key[i], 64) = 8
+    # BaseSumGate<2> rows of 63 limbs; the rest ArithmeticGate
+    assert c.gate_ops["PoseidonGate"] == 20 and c.gate_ops["BaseSumGate"] == 8
+    assert {g["type"] for g in c.gates} == {synth.GATE_NOOP, synth.GATE_CONSTANT, synth.GATE_PUBLIC_INPUT, synth.GATE_ARITHMETIC,
+                                            synth.GATE_POSEIDON, synth.GATE_BASE_SUM}
+    assert c.degree_bits == 7 and len(c.public_inputs) == 0
+    # one circuit, any witness: a non-inclusion proof and a disabled proof have the same structure
+    for other in (G.smt_inclusion_circuit(t, H(7)), G.smt_inclusion_circuit(t, H(5), enabled=False), G.smt_inclusion_circuit(G.SparseMerkleTree(), H(3))):
+        assert other.gates == c.gates and (other.constants == c.constants).all() and (other.sigmas == c.sigmas).all()
+    # a wrong root cannot even be wired: the witness would break a copy constraint
+    bad = reference_tree()
+    bad.root = (1, 2, 3, 4)
+    bad.nodes[bad.root] = t.nodes[t.root]
+    with pytest.raises(ValueError):
+        G.smt_inclusion_circuit(bad, H(5))
+
+
+@pytest.mark.parametrize("case", ["inclusion", "non-inclusion", "empty tree", "disabled", "public inputs"])
+def test_checker_proves_and_verifies(oracle, case):
+    t = reference_tree()
+    if case == "inclusion":
+        c = G.smt_inclusion_circuit(t, H(5))
+    elif case == "non-inclusion":
+        c = G.smt_inclusion_circuit(t, H(7))
+        assert not c.smt_witness["found"]
+    elif case == "empty tree":
+        c = G.smt_inclusion_circuit(G.SparseMerkleTree(), H(3))
+        assert c.smt_witness["is_old0"]
+    elif case == "disabled":
+        c = G.smt_inclusion_circuit(t, H(12), enabled=False)
+    else:
+        c = G.smt_inclusion_circuit(t, H(12), public=True)
+        assert [int(x) for x in c.public_inputs] == list(t.root) + list(H(12)) + list(H(1))
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0
+    if case == "public inputs":
+        bad = proof.copy()
+        bad[-1] = np.uint64(2)                                # claim another value for the key
+        assert oc.verify(bad) != 0
+    if case == "inclusion":
+        # flip one key bit in the witness (a BaseSumGate limb and nothing else): the copy constraints no longer hold
+        gi = next(i for i, g in enumerate(c.gates) if g["type"] == synth.GATE_BASE_SUM)
+        row = int(np.nonzero(c.constants[c.gates[gi]["selector_index"]] == np.uint64(gi))[0][0])
+        w = c.wires.copy()
+        w[1, row] ^= np.uint64(1)
+        rc, p2 = oc.prove(wires=w)
+        assert rc != 0 or oc.verify(p2) != 0
+
+
+def test_calc_node_hash_circuit(oracle):
+    """`test_calc_node_hash` [REF src/smt/gadgets/common.rs:27-85]: leaf hash and internal hash with and without the swap, in circuit,
+    registered as public inputs, equal to the native hashes."""
+    gb = G.GadgetBuilder()
+    key, value = [gb.target(x) for x in H(1)], [gb.target(x) for x in H(2)]
+    out1 = G._calc_leaf_hash(gb, key, value)
+    out2 = G._calc_internal_hash(gb, key, value, gb.constant_bool(False))
+    out3 = G._calc_internal_hash(gb, key, value, gb.constant_bool(True))
+    for t in out1 + out2 + out3:
+        gb.register_public_input(t)
+    c = gb.build()
+    T = G.SparseMerkleTree
+    assert [int(x) for x in c.public_inputs] == list(T.leaf_hash(H(1), H(2))) + list(T.internal_hash(H(1), H(2))) + list(T.internal_hash(H(2), H(1)))
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0

@@ -785,8 +785,18 @@ __global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, QProof p0, QBatc
 // gate_terms<.., HEAD_ONLY = true>.
 // `extra`: HBM-bound gates without limb work of their own kind (ComparisonGate) evaluated in the same launch, for the same
 // reason as the light gates in k_quotient: their loads overlap the limb gates' arithmetic.
-constexpr int LIMB_SLOTS = 4;
-struct LimbArgs { const u64 *desc; u32 count, jlo, jhi; u32 gi[LIMB_SLOTS]; u32 extra_count, extra_gi[4]; };
+// More than four limb gates (the real secp256k1 circuit has ten: U32Arithmetic, seven U32AddMany parameter sets, U32RangeCheck,
+// U32Subtraction) go through the same launch in GROUPS of four: the accumulators are reused, the wire planes of a later group are read
+// again by the same thread shortly after the first time (served mostly by the last-level cache, not HBM).
+constexpr int LIMB_SLOTS = 4, LIMB_GROUPS = 4;
+struct LimbArgs { const u64 *desc; u32 groups, num_wires; u32 count[LIMB_GROUPS], jlo[LIMB_GROUPS], jhi[LIMB_GROUPS]; u32 gi[LIMB_GROUPS][LIMB_SLOTS]; u32 extra_count, extra_gi[4]; };
+inline void limb_args(const glp_circuit *cc, LimbArgs &la) {
+    la.desc = cc->dev_limb_desc; la.groups = cc->limb_groups; la.num_wires = cc->d.num_wires;
+    for (int g = 0; g < LIMB_GROUPS; g++) {
+        la.count[g] = cc->limb_gcount[g]; la.jlo[g] = cc->limb_jlo[g]; la.jhi[g] = cc->limb_jhi[g];
+        for (int i = 0; i < LIMB_SLOTS; i++) la.gi[g][i] = cc->limb_gi[g * LIMB_SLOTS + i];
+    }
+}
 template <int NCH>
 __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, QBatch qb, LimbArgs la) {
     const QProof p = q_proof(p0, qb);
@@ -798,60 +808,65 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
     const u32 k0 = (u32)NCH + (u32)NCH * (a.npp + 1), nt = a.nterms;
     const u64 *W = p.wl + slot;
     const u64 *ap = p.apl + 2 * (size_t)k0;
-    AccHL ga[LIMB_SLOTS][MAXCH];
-    Base4Sum bs[LIMB_SLOTS];
-    _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
-        b4_zero(bs[s]);
-        _Pragma("unroll") for (int c = 0; c < NCH; c++) acc3_zero(ga[s][c]);
-    }
-    // heads
-    _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
-        if ((u32)s < la.count) {
-            const DevGate g = a.gates[la.gi[s]];
-            switch (g.type) {
-            case GLP_GATE_U32_ARITHMETIC: gate_terms<NCH, GLP_GATE_U32_ARITHMETIC, true>(a, p, g, N, slot, k0, ga[s]); break;
-            case GLP_GATE_U32_ADD_MANY: gate_terms<NCH, GLP_GATE_U32_ADD_MANY, true>(a, p, g, N, slot, k0, ga[s]); break;
-            case GLP_GATE_U32_SUBTRACTION: gate_terms<NCH, GLP_GATE_U32_SUBTRACTION, true>(a, p, g, N, slot, k0, ga[s]); break;
-            default: break;                    // U32RangeCheck: limb work only
-            }
-        }
-    }
+    u64 acc[MAXCH];
+    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
 #define LIMB_EMIT(S, K, V)                                                                                     \
     do {                                                                                                       \
         const u64 _v = (V);                                                                                    \
         _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[S][c2], _v, ap + 2 * ((size_t)c2 * nt + (K)));   \
     } while (0)
-    for (u32 j0 = la.jlo; j0 <= la.jhi; j0 += 8) {
-        u64 lv[8];
-        _Pragma("unroll") for (int t = 0; t < 8; t++) if (j0 + t <= la.jhi) lv[t] = W[(size_t)(j0 + t) * N];
-        _Pragma("unroll") for (int t = 0; t < 8; t++) if (j0 + t <= la.jhi) {
-            const u64 v = lv[t];
-            const u64 *dj = la.desc + (size_t)(j0 + t) * LIMB_SLOTS;
-            const u64 rp = range_product(v, 4);
-            _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
-                const u64 d = dj[s];
-                if (d & 1) {
-                    const u32 kl = (u32)(d >> 6) & 0x3FFu;
-                    _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[s][c2], rp, ap + 2 * ((size_t)c2 * nt + kl));
-                    b4_add(bs[s], v, (u32)(d >> 1) & 15u);
-                    if (d & 32) {
-                        const u32 kf = (u32)(d >> 16) & 0x3FFu, ref = (u32)(d >> 26) & 0xFFu;
-                        LIMB_EMIT(s, kf, sub(b4_value(bs[s]), W[(size_t)ref * N]));
-                        b4_zero(bs[s]);
+#pragma unroll 1
+    for (u32 grp = 0; grp < la.groups; grp++) {
+        const u32 gcount = la.count[grp], jlo = la.jlo[grp], jhi = la.jhi[grp];
+        const u64 *desc = la.desc + (size_t)grp * la.num_wires * LIMB_SLOTS;
+        AccHL ga[LIMB_SLOTS][MAXCH];
+        Base4Sum bs[LIMB_SLOTS];
+        _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+            b4_zero(bs[s]);
+            _Pragma("unroll") for (int c = 0; c < NCH; c++) acc3_zero(ga[s][c]);
+        }
+        // heads
+        _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+            if ((u32)s < gcount) {
+                const DevGate g = a.gates[la.gi[grp][s]];
+                switch (g.type) {
+                case GLP_GATE_U32_ARITHMETIC: gate_terms<NCH, GLP_GATE_U32_ARITHMETIC, true>(a, p, g, N, slot, k0, ga[s]); break;
+                case GLP_GATE_U32_ADD_MANY: gate_terms<NCH, GLP_GATE_U32_ADD_MANY, true>(a, p, g, N, slot, k0, ga[s]); break;
+                case GLP_GATE_U32_SUBTRACTION: gate_terms<NCH, GLP_GATE_U32_SUBTRACTION, true>(a, p, g, N, slot, k0, ga[s]); break;
+                default: break;                    // U32RangeCheck: limb work only
+                }
+            }
+        }
+        for (u32 j0 = jlo; j0 <= jhi; j0 += 8) {
+            u64 lv[8];
+            _Pragma("unroll") for (int t = 0; t < 8; t++) if (j0 + t <= jhi) lv[t] = W[(size_t)(j0 + t) * N];
+            _Pragma("unroll") for (int t = 0; t < 8; t++) if (j0 + t <= jhi) {
+                const u64 v = lv[t];
+                const u64 *dj = desc + (size_t)(j0 + t) * LIMB_SLOTS;
+                const u64 rp = range_product(v, 4);
+                _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+                    const u64 d = dj[s];
+                    if (d & 1) {
+                        const u32 kl = (u32)(d >> 6) & 0x3FFu;
+                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[s][c2], rp, ap + 2 * ((size_t)c2 * nt + kl));
+                        b4_add(bs[s], v, (u32)(d >> 1) & 15u);
+                        if (d & 32) {
+                            const u32 kf = (u32)(d >> 16) & 0x3FFu, ref = (u32)(d >> 26) & 0xFFu;
+                            LIMB_EMIT(s, kf, sub(b4_value(bs[s]), W[(size_t)ref * N]));
+                            b4_zero(bs[s]);
+                        }
                     }
                 }
             }
         }
-    }
-#undef LIMB_EMIT
-    u64 acc[MAXCH];
-    _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
-    _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
-        if ((u32)s < la.count) {
-            const u64 filter = gate_filter(a, a.gates[la.gi[s]], N, slot);
-            _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc3_reduce(ga[s][c])));
+        _Pragma("unroll") for (int s = 0; s < LIMB_SLOTS; s++) {
+            if ((u32)s < gcount) {
+                const u64 filter = gate_filter(a, a.gates[la.gi[grp][s]], N, slot);
+                _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = add(acc[c], mul(filter, acc3_reduce(ga[s][c])));
+            }
         }
     }
+#undef LIMB_EMIT
     for (u32 t = 0; t < la.extra_count; t++) {             // after the limb accumulators are dead (register budget)
         const DevGate g = a.gates[la.extra_gi[t]];
         if (g.type == GLP_GATE_COMPARISON) gate_contrib<NCH, GLP_GATE_COMPARISON>(a, p, g, N, slot, k0, acc);
@@ -1390,8 +1405,7 @@ struct glp_session {
             if (a.gate_mode == 1) {
                 if (cc->limb_count) {
                     LimbArgs la;
-                    la.desc = cc->dev_limb_desc; la.count = cc->limb_count; la.jlo = cc->limb_jlo; la.jhi = cc->limb_jhi;
-                    for (int i = 0; i < LIMB_SLOTS; i++) la.gi[i] = cc->limb_gi[i];
+                    limb_args(cc, la);
                     la.extra_count = cc->limb_extra_count;
                     for (int i = 0; i < 4; i++) la.extra_gi[i] = cc->limb_extra_gi[i];
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_quotient_limbs<2>), dim3(nblk(n), Rq), dim3(256), 0, c->stream, a, qp, qbt, la);
@@ -1736,11 +1750,12 @@ template <class F> void walk_proof(const glp_circuit *cc, F f) {
 // k_quotient_limbs (format: see the kernel).
 static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
     const glp_circuit_desc &d = cc->d;
-    std::vector<u64> desc((size_t)d.num_wires * LIMB_SLOTS, 0);
-    u32 jlo = d.num_wires, jhi = 0;
-    auto put = [&](u32 slot, u32 col, u32 pos, u32 kl, bool flush, u32 kf, u32 ref) {
-        desc[(size_t)col * LIMB_SLOTS + slot] = 1ull | ((u64)pos << 1) | (flush ? 32ull : 0ull) | ((u64)kl << 6) | ((u64)kf << 16) | ((u64)ref << 26);
-        jlo = std::min(jlo, col); jhi = std::max(jhi, col);
+    std::vector<u64> desc((size_t)LIMB_GROUPS * d.num_wires * LIMB_SLOTS, 0);
+    for (int g = 0; g < LIMB_GROUPS; g++) { cc->limb_jlo[g] = d.num_wires; cc->limb_jhi[g] = 0; }
+    auto put = [&](u32 s, u32 col, u32 pos, u32 kl, bool flush, u32 kf, u32 ref) {       // s = slot over all groups
+        const u32 grp = s / LIMB_SLOTS, slot = s % LIMB_SLOTS;
+        desc[((size_t)grp * d.num_wires + col) * LIMB_SLOTS + slot] = 1ull | ((u64)pos << 1) | (flush ? 32ull : 0ull) | ((u64)kl << 6) | ((u64)kf << 16) | ((u64)ref << 26);
+        cc->limb_jlo[grp] = std::min(cc->limb_jlo[grp], col); cc->limb_jhi[grp] = std::max(cc->limb_jhi[grp], col);
     };
     for (u32 gi = 0; gi < d.num_gates; gi++) {
         const glp_gate &g = cc->gates[gi];
@@ -1750,7 +1765,7 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
                            g.type == GLP_GATE_BASE_SUM || g.type == GLP_GATE_RANDOM_ACCESS;
         // alpha indices and wire columns must fit the descriptor fields (10 and 8 bits); glp_circuit_create has already
         // bounded num_constraints by ACC_MAX_TERMS = 1024
-        if (limb_gate && cc->limb_count < (u32)LIMB_SLOTS && d.num_wires <= 256) {
+        if (limb_gate && cc->limb_count < (u32)(LIMB_SLOTS * LIMB_GROUPS) && d.num_wires <= 256) {
             const u32 s = cc->limb_count++;
             cc->limb_gi[s] = gi;
             if (g.type == GLP_GATE_U32_ARITHMETIC) {
@@ -1793,7 +1808,8 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
         cc->single_gates.swap(keep);
     }
     if (cc->limb_count) {
-        cc->limb_jlo = jlo; cc->limb_jhi = jhi;
+        cc->limb_groups = (cc->limb_count + LIMB_SLOTS - 1) / LIMB_SLOTS;
+        for (u32 g = 0; g < cc->limb_groups; g++) cc->limb_gcount[g] = std::min<u32>(LIMB_SLOTS, cc->limb_count - g * LIMB_SLOTS);
         GLP_TRY(c->alloc((void **)&cc->dev_limb_desc, desc.size() * 8));
         GLP_TRY(h2d(c, cc->dev_limb_desc, desc.data(), desc.size() * 8));
     }

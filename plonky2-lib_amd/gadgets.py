@@ -52,13 +52,31 @@ def _deinterleave(v):
     return v
 
 
+def _batch_inverse(values):
+    """inverses mod p of non-zero integers with one exponentiation (Montgomery's trick)"""
+    n = len(values)
+    if n == 0:
+        return np.zeros(0, np.uint64)
+    pre, acc = [0] * n, 1
+    for i, v in enumerate(values):
+        pre[i] = acc
+        acc = acc * v % P
+    inv = pow(acc, P - 2, P)
+    out = np.empty(n, np.uint64)
+    for i in range(n - 1, -1, -1):
+        out[i] = inv * pre[i] % P
+        inv = inv * values[i] % P
+    return out
+
+
 class GadgetBuilder:
     """Targets are integer ids; `self.val[t]` is the value the witness assigns."""
 
     def __init__(self, config=None):
         self.cfg = config or synth.Config.standard_recursion_config()
         nw, nr = self.cfg.num_wires, self.cfg.num_routed_wires
-        self.val, self._parent, self._cells = [], [], []
+        self.val, self._parent = [], []
+        self._cell_t, self._cell_r, self._cell_c = [], [], []      # every routed cell: (target, row, column)
         self.rows = []                 # per row: [gate type, p0, p1, (const0, const1)]
         self._open = {}                # slot key -> [row, next free op]
         self._ops = {t: [] for t in (GATE_U32_ARITHMETIC, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_U32,
@@ -77,7 +95,6 @@ class GadgetBuilder:
     def target(self, value):
         self.val.append(int(value) % P)
         self._parent.append(len(self.val) - 1)
-        self._cells.append([])
         return len(self.val) - 1
 
     def _find(self, t):
@@ -95,7 +112,7 @@ class GadgetBuilder:
 
     def _place(self, t, row, col):
         assert col < self.cfg.num_routed_wires
-        self._cells[t].append((row, col))
+        self._cell_t.append(t); self._cell_r.append(row); self._cell_c.append(col)
 
     def _wire(self, row, col, value):
         """a fresh target living in cell (row, col)"""
@@ -342,9 +359,7 @@ class GadgetBuilder:
         poseidon_rows = self._poseidon_rows
         nrows = len(self.rows)
         log_n = max(min_log_n, 2, (nrows - 1).bit_length())
-        b = synth.Builder(cfg, log_n, seed=0)
-        used = np.arange(nrows)
-        b.wires[:, used] = 0
+        b = synth.Builder(cfg, log_n, seed=0, random_from_row=nrows)
         by_kind = {}
         for r, (g, p0, p1, consts) in enumerate(self.rows):
             by_kind.setdefault((g, p0, p1), []).append(r)
@@ -353,17 +368,31 @@ class GadgetBuilder:
                     b.gate_consts[k, r] = c
         for (g, p0, p1), rr in by_kind.items():
             b.set_rows(np.array(rr), g, p0, p1)
-        # routed cells of every target; one sigma cycle per connected class
-        classes = {}
-        for t in range(len(self.val)):
-            if self._cells[t]:
-                classes.setdefault(self._find(t), []).extend(self._cells[t])
-            for (r, c) in self._cells[t]:
-                b.wires[c, r] = self.val[t]
-        for cells in classes.values():
-            if len(cells) > 1:
-                assert len(set(cells)) == len(cells)
-                b.connect_cycle([r for r, _ in cells], [c for _, c in cells])
+        # routed cells of every target; one sigma cycle per connected class (all in numpy: a 2^20-row circuit has ~10^7 cells)
+        ct = np.array(self._cell_t, dtype=np.int64)
+        cr = np.array(self._cell_r, dtype=np.int64)
+        cc = np.array(self._cell_c, dtype=np.int64)
+        flat = cr * cfg.num_routed_wires + cc
+        assert len(np.unique(flat)) == len(flat), "a routed cell was assigned twice"
+        vals = np.array(self.val, dtype=np.uint64)
+        b.wires[cc, cr] = vals[ct]
+        par = np.array(self._parent, dtype=np.int64)
+        while True:                                           # pointer jumping: every target -> the root of its class
+            nxt = par[par]
+            if (nxt == par).all():
+                break
+            par = nxt
+        root = par[ct]
+        order = np.argsort(root, kind="stable")
+        sr, sc, sroot = cr[order], cc[order], root[order]
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = sroot[1:] != sroot[:-1]
+        start = np.maximum.accumulate(np.where(first, np.arange(len(order)), 0))     # index of the first cell of each cell's class
+        last = np.ones(len(order), dtype=bool)
+        last[:-1] = first[1:]
+        nxt_idx = np.where(last, start, np.arange(len(order)) + 1)                    # successor within the class, cyclically
+        b.sig_row[sc, sr] = sr[nxt_idx]
+        b.sig_col[sc, sr] = sc[nxt_idx]
         # advice wires (what the gates' row-local generators produce), vectorised per gate type
         w = b.wires
 
@@ -374,15 +403,14 @@ class GadgetBuilder:
             return (np.array([x[0] for x in a]), np.array([x[1] for x in a]), np.array([x[2] for x in a], dtype=np.uint64))
         # every U32ArithmeticGate slot (used or not) needs inverse = 1 / (2^32 - 1 - output_high)
         inv_free = pow(M32, P - 2, P)
-        for r, (g, p0, p1, _) in enumerate(self.rows):
-            if g == GATE_U32_ARITHMETIC:
-                for i in range(p0):
-                    w[6 * i + 5, r] = inv_free
+        ua_rows = np.array([r for r, row in enumerate(self.rows) if row[0] == GATE_U32_ARITHMETIC], dtype=np.int64)
+        for i in range(self.n_u32a):
+            w[6 * i + 5, ua_rows] = inv_free
         rc = recs(GATE_U32_ARITHMETIC)
         if rc is not None:
             rr, ii, prod = rc
             hi = prod >> np.uint64(32)
-            w[6 * ii + 5, rr] = [pow((M32 - int(h)) % P, P - 2, P) for h in hi]
+            w[6 * ii + 5, rr] = _batch_inverse([M32 - int(h) for h in hi])
             for k in range(32):
                 w[6 * self.n_u32a + 32 * ii + k, rr] = (prod >> np.uint64(2 * k)) & np.uint64(3)
         rc = recs(GATE_U32_SUBTRACTION)

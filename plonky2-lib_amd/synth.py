@@ -117,14 +117,20 @@ def _selector_groups(gates, max_degree):
 
 
 class Builder:
-    def __init__(self, config, log_n, seed=0):
+    def __init__(self, config, log_n, seed=0, random_from_row=0):
+        """random_from_row: rows below it start as zeros (a caller that fills them all saves the random draw)"""
         self.cfg, self.log_n, self.n = config, log_n, 1 << log_n
         self.rng = np.random.default_rng(seed)
         n, nw, nr = self.n, config.num_wires, config.num_routed_wires
         self.row_gate = np.zeros(n, dtype=np.int64)            # per row: key into self.gate_kinds
         self.gate_kinds = {}                                   # (type, p0) -> key
         self.gate_consts = np.zeros((config.num_constants, n), dtype=np.uint64)
-        self.wires = gl.rand(self.rng, (nw, n))                # unconstrained cells stay random
+        if random_from_row:                                    # unconstrained cells stay random
+            self.wires = np.zeros((nw, n), dtype=np.uint64)
+            if random_from_row < n:
+                self.wires[:, random_from_row:] = gl.rand(self.rng, (nw, n - random_from_row))
+        else:
+            self.wires = gl.rand(self.rng, (nw, n))
         self.sig_row = np.tile(np.arange(n, dtype=np.int64), (nr, 1))
         self.sig_col = np.tile(np.arange(nr, dtype=np.int64)[:, None], (1, n))
         self.public_inputs = np.zeros(0, dtype=np.uint64)

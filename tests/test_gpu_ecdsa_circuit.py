@@ -1,0 +1,68 @@
+"""BASELINE config 3 on the GPU as the REAL circuit: the reference's `verify_message_circuit` [REF src/ecdsa/gadgets/ecdsa.rs:136-159] rebuilt in
+plonky2-lib_amd/gadgets_ecdsa.py (98 687 rows per signature: nonnative secp256k1 arithmetic on u32 limbs, 4-bit windowed fixed-base
+multiplication, GLV + 2-bit windowed double-scalar multiplication), proved by the HIP library through the C ABI -- mirrors
+`test_batch_ecdsa_circuit_with_config` [REF src/ecdsa/gadgets/ecdsa.rs:214-353]: prove, then verify."""
+import numpy as np
+import pytest
+
+import plonky2_lib_amd as glp
+from plonky2_lib_amd import gadgets_ecdsa as E
+from test_oracle_witness import scramble_derived
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = glp.Context(0)
+    yield c
+    c.close()
+
+
+def test_one_signature(ctx, oracle):
+    sigs = E.random_signatures(2, seed=11)
+    c = E.ecdsa_circuit(sigs[:1])
+    assert c.degree_bits == 17
+    gc = glp.Circuit(ctx, c)
+    oc = oracle.OracleCircuit(c)
+    proof = gc.prove()
+    assert gc.verify(proof) and oc.verify(proof) == 0
+    rc, ref = oc.prove()                                       # the checker's prover on the same 2^17-row witness
+    assert rc == 0 and (proof == ref).all(), "first mismatch at word %d" % int(np.argmax(proof != ref))
+    bad = proof.copy()
+    bad[len(bad) // 3] ^= np.uint64(1)
+    assert not gc.verify(bad) and oc.verify(bad) != 0
+    # "build once": another signature is another witness of the same circuit
+    d = E.ecdsa_circuit(sigs[1:])
+    assert d.gates == c.gates and (d.sigmas == c.sigmas).all() and (d.constants == c.constants).all()
+    p2 = gc.prove(wires=d.wires)
+    assert gc.verify(p2) and not (p2 == proof).all()
+    # a witness with one limb of a product changed proves nothing
+    w = c.wires.copy()
+    import plonky2_lib_amd.synth as synth
+    gi = next(i for i, g in enumerate(c.gates) if g["type"] == synth.GATE_U32_ARITHMETIC)
+    row = int(np.nonzero(c.constants[c.gates[gi]["selector_index"]] == np.uint64(gi))[0][1000])
+    w[3, row] ^= np.uint64(1)
+    assert not gc.verify(gc.prove(wires=w))
+    # GPU witness generation: all advice columns (2-bit limbs, comparison chunks, access bits, inverses) from the routed wires
+    ws, _ = scramble_derived(c, np.random.default_rng(3), only_advice=True)
+    ws = np.ascontiguousarray(ws)
+    dptr = ctx.dev_alloc(ws.nbytes)
+    ctx.dev_upload(dptr, ws)
+    gc.witness_fill(dptr, only_advice=True)
+    p3 = gc.prove_device(dptr)
+    ctx.dev_free(dptr)
+    assert gc.verify(p3)
+    gc.free()
+
+
+def test_two_signatures_batch_circuit(ctx, oracle):
+    """`batch_verify_message_circuit` [REF src/ecdsa/gadgets/ecdsa.rs:161-191] on two signatures: 2^18 rows (the fixed-base tables are shared)"""
+    c = E.ecdsa_circuit(E.random_signatures(2, seed=12))
+    assert c.degree_bits == 18 and 0 <= 2 * 98687 + 7714 + 1 - c.gadget_rows < 16        # partly filled rows are shared between the two
+    gc = glp.Circuit(ctx, c)
+    proof = gc.prove()
+    assert gc.verify(proof)
+    oc = oracle.OracleCircuit(c, cs_cap=gc.constants_sigmas_cap())
+    assert oc.verify(proof) == 0
+    gc.free()

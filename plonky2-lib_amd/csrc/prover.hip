@@ -1757,6 +1757,33 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
         desc[((size_t)grp * d.num_wires + col) * LIMB_SLOTS + slot] = 1ull | ((u64)pos << 1) | (flush ? 32ull : 0ull) | ((u64)kl << 6) | ((u64)kf << 16) | ((u64)ref << 26);
         cc->limb_jlo[grp] = std::min(cc->limb_jlo[grp], col); cc->limb_jhi[grp] = std::max(cc->limb_jhi[grp], col);
     };
+    std::vector<u32> limb_list;
+    auto fill = [&](u32 s, u32 gi) {               // column program of gate gi in slot s (= 4 group + slot)
+        const glp_gate &g = cc->gates[gi];
+        cc->limb_gi[s] = gi;
+        if (g.type == GLP_GATE_U32_ARITHMETIC) {
+            for (u32 i = 0; i < g.p0; i++)
+                for (u32 j = 0; j < 32; j++)
+                    put(s, 6 * g.p0 + 32 * i + j, j & 15, 36 * i + 2 + (31 - j), (j & 15) == 15, 36 * i + 34 + (j >> 4), 6 * i + 3 + (j >> 4));
+        } else if (g.type == GLP_GATE_U32_ADD_MANY) {
+            const u32 na = g.p0, nops = g.p1, wd = na + 3;
+            for (u32 i = 0; i < nops; i++)
+                for (u32 j = 0; j < 18; j++)
+                    put(s, wd * nops + 18 * i + j, j & 15, 21 * i + 1 + (17 - j), j == 15 || j == 17, 21 * i + 19 + (j >> 4), wd * i + na + 1 + (j >> 4));
+        } else if (g.type == GLP_GATE_U32_SUBTRACTION) {
+            for (u32 i = 0; i < g.p0; i++)
+                for (u32 j = 0; j < 16; j++)
+                    put(s, 5 * g.p0 + 16 * i + j, j, 19 * i + 1 + (15 - j), j == 15, 19 * i + 17, 5 * i + 3);
+        } else {
+            for (u32 i = 0; i < g.p0; i++)
+                for (u32 j = 0; j < 16; j++)
+                    put(s, g.p0 + 16 * i + j, j, 17 * i + 1 + j, j == 15, 17 * i, i);
+        }
+    };
+    auto limb_weight = [&](u32 gi) -> u32 {        // limb columns of the gate = its share of the per-point work
+        const glp_gate &g = cc->gates[gi];
+        return g.type == GLP_GATE_U32_ARITHMETIC ? 32 * g.p0 : g.type == GLP_GATE_U32_ADD_MANY ? 18 * g.p1 : 16 * g.p0;
+    };
     for (u32 gi = 0; gi < d.num_gates; gi++) {
         const glp_gate &g = cc->gates[gi];
         const bool limb_gate = g.type == GLP_GATE_U32_ARITHMETIC || g.type == GLP_GATE_U32_ADD_MANY ||
@@ -1765,27 +1792,8 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
                            g.type == GLP_GATE_BASE_SUM || g.type == GLP_GATE_RANDOM_ACCESS;
         // alpha indices and wire columns must fit the descriptor fields (10 and 8 bits); glp_circuit_create has already
         // bounded num_constraints by ACC_MAX_TERMS = 1024
-        if (limb_gate && cc->limb_count < (u32)(LIMB_SLOTS * LIMB_GROUPS) && d.num_wires <= 256) {
-            const u32 s = cc->limb_count++;
-            cc->limb_gi[s] = gi;
-            if (g.type == GLP_GATE_U32_ARITHMETIC) {
-                for (u32 i = 0; i < g.p0; i++)
-                    for (u32 j = 0; j < 32; j++)
-                        put(s, 6 * g.p0 + 32 * i + j, j & 15, 36 * i + 2 + (31 - j), (j & 15) == 15, 36 * i + 34 + (j >> 4), 6 * i + 3 + (j >> 4));
-            } else if (g.type == GLP_GATE_U32_ADD_MANY) {
-                const u32 na = g.p0, nops = g.p1, wd = na + 3;
-                for (u32 i = 0; i < nops; i++)
-                    for (u32 j = 0; j < 18; j++)
-                        put(s, wd * nops + 18 * i + j, j & 15, 21 * i + 1 + (17 - j), j == 15 || j == 17, 21 * i + 19 + (j >> 4), wd * i + na + 1 + (j >> 4));
-            } else if (g.type == GLP_GATE_U32_SUBTRACTION) {
-                for (u32 i = 0; i < g.p0; i++)
-                    for (u32 j = 0; j < 16; j++)
-                        put(s, 5 * g.p0 + 16 * i + j, j, 19 * i + 1 + (15 - j), j == 15, 19 * i + 17, 5 * i + 3);
-            } else {
-                for (u32 i = 0; i < g.p0; i++)
-                    for (u32 j = 0; j < 16; j++)
-                        put(s, g.p0 + 16 * i + j, j, 17 * i + 1 + j, j == 15, 17 * i, i);
-            }
+        if (limb_gate && limb_list.size() < (size_t)(LIMB_SLOTS * LIMB_GROUPS) && d.num_wires <= 256) {
+            limb_list.push_back(gi);                       // slots are assigned below, once all limb gates are known
         } else if (g.type == GLP_GATE_ARITHMETIC && cc->arith_ops == 0 && 4 * g.p0 <= d.num_routed_wires && d.quotient_degree_factor % 4 == 0 &&
                    d.num_selectors + 2 <= d.num_constants) {
             cc->arith_gi = gi; cc->arith_ops = g.p0;      // evaluated inside the permutation loop of k_quotient
@@ -1795,9 +1803,25 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
             cc->single_gates.push_back(gi);
         }
     }
-    if (cc->limb_count == 1) {                 // nothing to share: the gate's own kernel is the better launch
-        cc->single_gates.push_back(cc->limb_gi[0]);
-        cc->limb_count = 0;
+    if (limb_list.size() == 1) {               // nothing to share: the gate's own kernel is the better launch
+        cc->single_gates.push_back(limb_list[0]);
+        limb_list.clear();
+    }
+    if (!limb_list.empty()) {
+        // Up to four gates share a set of accumulators (one group); more gates go through the same launch group after group.  The
+        // fewest groups that hold them (every group recomputes the range products of its columns), filled heaviest first.
+        const u32 cnt = (u32)limb_list.size();
+        const u32 G = (cnt + LIMB_SLOTS - 1) / LIMB_SLOTS;
+        u32 load[LIMB_GROUPS] = {0, 0, 0, 0}, used[LIMB_GROUPS] = {0, 0, 0, 0};
+        std::stable_sort(limb_list.begin(), limb_list.end(), [&](u32 x, u32 y) { return limb_weight(x) > limb_weight(y); });
+        for (u32 gi : limb_list) {
+            u32 best = G;
+            for (u32 g = 0; g < G; g++) if (used[g] < (u32)LIMB_SLOTS && (best == G || load[g] < load[best])) best = g;
+            fill(best * LIMB_SLOTS + used[best], gi);
+            used[best]++; load[best] += limb_weight(gi);
+        }
+        cc->limb_count = cnt; cc->limb_groups = G;
+        for (u32 g = 0; g < G; g++) cc->limb_gcount[g] = used[g];
     }
     if (cc->limb_count) {                      // ComparisonGate (HBM-bound) rides with the VALU-bound limb launch
         std::vector<u32> keep;
@@ -1808,8 +1832,6 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
         cc->single_gates.swap(keep);
     }
     if (cc->limb_count) {
-        cc->limb_groups = (cc->limb_count + LIMB_SLOTS - 1) / LIMB_SLOTS;
-        for (u32 g = 0; g < cc->limb_groups; g++) cc->limb_gcount[g] = std::min<u32>(LIMB_SLOTS, cc->limb_count - g * LIMB_SLOTS);
         GLP_TRY(c->alloc((void **)&cc->dev_limb_desc, desc.size() * 8));
         GLP_TRY(h2d(c, cc->dev_limb_desc, desc.data(), desc.size() * 8));
     }

@@ -39,6 +39,14 @@ def test_single_rank_line_has_roofline_verified_and_variants():
     assert v["gpu_witness_fill_advice_columns"]["same_proof_after_fill"] is True
 
 
+def test_headline_line_on_the_real_circuit():
+    """--log-n 17: the smallest instance of the real secp256k1 circuit (one signature per proof) through the default code path"""
+    d = _run(["--log-n", "17", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["verified"] is True and d["config"]["signatures_per_proof"] == 1 and "98 687 rows per signature" in d["config"]["workload"]
+    assert d["variants"]["gate_mix_stand_in"]["verified"] is True
+    assert d["variants"]["gpu_witness_fill_advice_columns"]["same_proof_after_fill"] is True
+
+
 def test_zkdsa_batch_workload_line():
     d = _run(["--workload", "zkdsa-batch", "--batch", "64", "--sub-batch", "32", "--threads", "2", "--steps", "1", "--warmup", "1"])
     assert d["verified"] is True and d["value"] > 0 and "glp_prove_batch" in d["config"]["workload"]

@@ -37,7 +37,35 @@ def random_case(rng):
     family = "arith"
     seed = int(rng.integers(1, 1 << 30))
     if qdf >= 8 and rng.random() < 0.75:       # PoseidonGate (degree 7) and the reference's u32 gates need quotient degree factor 8
-        family = str(rng.choice(["poseidon_chain", "u32", "zkdsa", "keccak", "smt"]))
+        family = str(rng.choice(["poseidon_chain", "u32", "zkdsa", "keccak", "smt", "real_smt", "real_keccak", "real_curve"]))
+    if family.startswith("real_"):
+        # the reference's own circuits rebuilt gadget for gadget (gadgets.py / gadgets_ecdsa.py) on random inputs, under the random FRI / challenge
+        # configuration drawn above; 135 wires for the hash circuits, 136 for the curve gadgets (U32RangeCheckGate of 8 limbs)
+        from plonky2_lib_amd import gadgets, gadgets_ecdsa
+        if family == "real_smt":
+            tree = gadgets.SparseMerkleTree()
+            keys = [tuple(int(x) for x in rng.integers(0, 1 << 32, 4)) for _ in range(int(rng.integers(0, 40)))]
+            for k in keys:
+                tree.insert(k, tuple(int(x) for x in rng.integers(1, 1 << 32, 4)))
+            key = keys[int(rng.integers(0, len(keys)))] if keys and rng.random() < 0.6 else tuple(int(x) for x in rng.integers(0, 1 << 32, 4))
+            desc = gadgets.smt_inclusion_circuit(tree, key, config=synth.Config(135, 80, **kw), public=bool(rng.random() < 0.5),
+                                                 enabled=bool(rng.random() < 0.9))
+        elif family == "real_keccak":
+            desc = gadgets.keccak256_circuit(bytes(rng.integers(0, 256, int(rng.integers(0, 136)), dtype=np.uint8)), config=synth.Config(135, 80, **kw))
+        else:
+            eb = gadgets_ecdsa.EcdsaBuilder(synth.Config(136, 80, **kw))
+            a, b = int(rng.integers(1, 1 << 62)), int(rng.integers(1, 1 << 62))
+            p1, p2 = eb.virtual_affine_point(gadgets_ecdsa.pt_mul(a, gadgets_ecdsa.G)), eb.virtual_affine_point(gadgets_ecdsa.pt_mul(a + b, gadgets_ecdsa.G))
+            eb.curve_assert_valid(p1)
+            s = eb.curve_conditional_add(eb.curve_double(p1), p2, eb.target(int(rng.integers(0, 2))))
+            eb.random_access_curve_points(eb.target(int(rng.integers(0, 16))), [s, p1, p2, eb.curve_add(p1, p2)] * 4)
+            desc = eb.build()
+        if sum(desc.reduction_arity_bits) > desc.degree_bits:
+            return random_case(rng)
+        hasher = int(rng.random() < 0.3)
+        if hasher:
+            desc.hasher, desc.circuit_digest = 1, None
+        return desc, dict(family=family, lg=int(desc.degree_bits), wide=True, npi=len(desc.public_inputs), gate_rows=0, hasher=hasher, **kw)
     if family == "poseidon_chain":
         desc = synth.poseidon_chain_circuit(max(lg, 5), config, seed=seed)
     elif family == "u32":

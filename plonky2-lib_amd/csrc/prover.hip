@@ -260,20 +260,28 @@ __device__ __forceinline__ u64 acc2_reduce(const AccLimb &a) {    // canonical
 // The same carry-free scheme with the roles swapped, for the quotient: the multiplier alpha^k comes from a table the host
 // cuts into 22-bit limbs once per proof, so a constraint value enters as its two 32-bit halves -- the registers it already
 // lives in -- instead of being cut into three limbs per term (5 shift / mask slots per constraint, 620 constraints per point).
-struct AccHL { u64 b00, b01, b02, b10, b11, b12; };       // b[i][j]: half i of v (bits 32 i ..) times limb j of m (bits 22 j ..)
-__device__ __forceinline__ void acc3_zero(AccHL &a) { a.b00 = a.b01 = a.b02 = a.b10 = a.b11 = a.b12 = 0; }
-__device__ __forceinline__ void acc3_fma(AccHL &a, u64 v, const u64 *ml /* {m0 | m1 << 32, m2} */) {
+// m enters TWICE, as m and as m' = m 2^32 mod p: then  v m = vlo m + vhi m'  and both products sit at the same limb weights, so
+// three accumulators per sum are enough (six if the 2^32 is left to the weights).  Half the registers per gate in the quotient
+// kernels -- what bounds how many gates share one pass over the wire planes -- for twice the (scalar) table loads.
+struct AccHL { u64 c0, c1, c2; };                         // c[j]: limb j of m (bits 22 j ..) times vlo + limb j of m' times vhi
+constexpr u32 ACC3_MAX_TERMS = 512;                       // 2 products < 2^54 per term and accumulator
+constexpr u32 APL_WORDS = 4;                              // table words per power: m0 | m1 << 32, m2, m0' | m1' << 32, m2'
+inline void apl_words(u64 m, u64 out[4]) {                // host side of the table
+    const u64 mp = glf::mul(m, 1ull << 32);
+    out[0] = (m & 0x3FFFFFull) | (((m >> 22) & 0x3FFFFFull) << 32); out[1] = m >> 44;
+    out[2] = (mp & 0x3FFFFFull) | (((mp >> 22) & 0x3FFFFFull) << 32); out[3] = mp >> 44;
+}
+__device__ __forceinline__ void acc3_zero(AccHL &a) { a.c0 = a.c1 = a.c2 = 0; }
+__device__ __forceinline__ void acc3_fma(AccHL &a, u64 v, const u64 *ml) {
     const u32 vlo = (u32)v, vhi = (u32)(v >> 32);
-    const u64 w0 = ml[0], w1 = ml[1];
-    const u32 m0 = (u32)w0, m1 = (u32)(w0 >> 32), m2 = (u32)w1;
-    a.b00 += (u64)vlo * m0; a.b01 += (u64)vlo * m1; a.b02 += (u64)vlo * m2;
-    a.b10 += (u64)vhi * m0; a.b11 += (u64)vhi * m1; a.b12 += (u64)vhi * m2;
+    const u64 w0 = ml[0], w1 = ml[1], w2 = ml[2], w3 = ml[3];
+    a.c0 += (u64)vlo * (u32)w0; a.c1 += (u64)vlo * (u32)(w0 >> 32); a.c2 += (u64)vlo * (u32)w1;
+    a.c0 += (u64)vhi * (u32)w2; a.c1 += (u64)vhi * (u32)(w2 >> 32); a.c2 += (u64)vhi * (u32)w3;
 }
 __device__ __forceinline__ u64 acc3_reduce(const AccHL &a) {      // canonical
     Acc160 w;
     acc_zero(w);
-    acc_add_shifted<0>(w, a.b00); acc_add_shifted<22>(w, a.b01); acc_add_shifted<32>(w, a.b10);
-    acc_add_shifted<44>(w, a.b02); acc_add_shifted<54>(w, a.b11); acc_add_shifted<76>(w, a.b12);
+    acc_add_shifted<0>(w, a.c0); acc_add_shifted<22>(w, a.c1); acc_add_shifted<44>(w, a.c2);
     return acc_reduce(w);
 }
 
@@ -291,7 +299,7 @@ struct QProof {                     // per proof
     const u64 *wl, *zl;             // coset-major LDEs of the wires and of Z ++ partial products
     u64 *out;                       // [nch][Rq][n]
     const u64 *apow;                // [nch][nterms] powers of the alphas
-    const u64 *apl;                 // the same powers as 22-bit limbs, two words per power: m0 | m1 << 32, m2 (AccHL)
+    const u64 *apl;                 // the same powers as 22-bit limbs of m and of m 2^32, APL_WORDS words per power (AccHL)
     u64 betas[MAXCH], gammas[MAXCH], pih[4];
 };
 // many-proofs batch (glp_prove_batch): blockIdx.z = proof; arrays advance by a stride per proof, challenges and the public-input
@@ -302,7 +310,7 @@ __device__ __forceinline__ QProof q_proof(const QProof &p0, const QBatch &b) {
     QProof p = p0;
     if (b.pp) {
         const size_t k = blockIdx.z;
-        p.wl += k * b.wl_stride; p.zl += k * b.zl_stride; p.out += k * b.out_stride; p.apow += k * b.apow_stride; p.apl += 2 * k * b.apow_stride;
+        p.wl += k * b.wl_stride; p.zl += k * b.zl_stride; p.out += k * b.out_stride; p.apow += k * b.apow_stride; p.apl += APL_WORDS * k * b.apow_stride;
         const u64 *q = b.pp + k * 3 * MAXCH;
         _Pragma("unroll") for (int c = 0; c < MAXCH; c++) { p.betas[c] = q[c]; p.gammas[c] = q[MAXCH + c]; p.pih[c] = q[2 * MAXCH + c]; }
     }
@@ -346,11 +354,11 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
     const u64 *W = p.wl + slot;                       // wire j  -> W[j * N]
     const u64 *GC = a.cs + (size_t)a.nsel * N + slot; // gate constant i -> GC[i * N]
     {
-        const u64 *ap = p.apl + 2 * (size_t)k0;
+        const u64 *ap = p.apl + APL_WORDS * (size_t)k0;
 #define EMIT(k, v)                                                                     \
     do {                                                                               \
         const u64 _v = (v);                                                            \
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[c2], _v, ap + 2 * ((size_t)c2 * nt + (k)));   \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[c2], _v, ap + APL_WORDS * ((size_t)c2 * nt + (k)));   \
     } while (0)
 // Base-4 limb columns LIMBS[j*N], j = COUNT-1 .. 0: eight loads are issued before their values are used (the gate
 // loops have run-time bounds, so the compiler cannot software-pipeline them itself).  Constraint index KIDX may use _j.
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(256, GATES == 1 ? 3 : 4) void k_quotient(QArgs a, Q
                     if (jb + t + 3 < j1 && (jb + t) / 4 < ar_ops) {
                         const u32 i = (jb + t) / 4;
                         const u64 v = sub(w8[t + 3], add(mul(mul(w8[t], w8[t + 1]), ar_c0), mul(w8[t + 2], ar_c1)));
-                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(gar[c2], v, p.apl + 2 * ((size_t)c2 * nt + k0 + i));
+                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(gar[c2], v, p.apl + APL_WORDS * ((size_t)c2 * nt + k0 + i));
                     }
             }
 #pragma unroll
@@ -785,10 +793,11 @@ __global__ __launch_bounds__(256) void k_quotient_gate(QArgs a, QProof p0, QBatc
 // gate_terms<.., HEAD_ONLY = true>.
 // `extra`: HBM-bound gates without limb work of their own kind (ComparisonGate) evaluated in the same launch, for the same
 // reason as the light gates in k_quotient: their loads overlap the limb gates' arithmetic.
-// More than four limb gates (the real secp256k1 circuit has ten: U32Arithmetic, seven U32AddMany parameter sets, U32RangeCheck,
-// U32Subtraction) go through the same launch in GROUPS of four: the accumulators are reused, the wire planes of a later group are read
-// again by the same thread shortly after the first time (served mostly by the last-level cache, not HBM).
-constexpr int LIMB_SLOTS = 4, LIMB_GROUPS = 4;
+// More limb gates than slots (the real secp256k1 circuit has ten: U32Arithmetic, seven U32AddMany parameter sets, U32RangeCheck,
+// U32Subtraction) go through the same launch in GROUPS of LIMB_SLOTS (five: 123 VGPRs, four waves per SIMD; six cost a wave and
+// measured slower): the accumulators are reused; the wire planes are read again per group (PMC: from HBM, the last-level cache does
+// not hold them in between).
+constexpr int LIMB_SLOTS = 5, LIMB_GROUPS = 4;
 struct LimbArgs { const u64 *desc; u32 groups, num_wires; u32 count[LIMB_GROUPS], jlo[LIMB_GROUPS], jhi[LIMB_GROUPS]; u32 gi[LIMB_GROUPS][LIMB_SLOTS]; u32 extra_count, extra_gi[4]; };
 inline void limb_args(const glp_circuit *cc, LimbArgs &la) {
     la.desc = cc->dev_limb_desc; la.groups = cc->limb_groups; la.num_wires = cc->d.num_wires;
@@ -807,13 +816,13 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
     const size_t slot = (size_t)r * n + q;
     const u32 k0 = (u32)NCH + (u32)NCH * (a.npp + 1), nt = a.nterms;
     const u64 *W = p.wl + slot;
-    const u64 *ap = p.apl + 2 * (size_t)k0;
+    const u64 *ap = p.apl + APL_WORDS * (size_t)k0;
     u64 acc[MAXCH];
     _Pragma("unroll") for (int c = 0; c < NCH; c++) acc[c] = 0;
 #define LIMB_EMIT(S, K, V)                                                                                     \
     do {                                                                                                       \
         const u64 _v = (V);                                                                                    \
-        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[S][c2], _v, ap + 2 * ((size_t)c2 * nt + (K)));   \
+        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[S][c2], _v, ap + APL_WORDS * ((size_t)c2 * nt + (K)));   \
     } while (0)
 #pragma unroll 1
     for (u32 grp = 0; grp < la.groups; grp++) {
@@ -848,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void k_quotient_limbs(QArgs a, QProof p0, Q
                     const u64 d = dj[s];
                     if (d & 1) {
                         const u32 kl = (u32)(d >> 6) & 0x3FFu;
-                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[s][c2], rp, ap + 2 * ((size_t)c2 * nt + kl));
+                        _Pragma("unroll") for (int c2 = 0; c2 < NCH; c2++) acc3_fma(ga[s][c2], rp, ap + APL_WORDS * ((size_t)c2 * nt + kl));
                         b4_add(bs[s], v, (u32)(d >> 1) & 15u);
                         if (d & 32) {
                             const u32 kf = (u32)(d >> 16) & 0x3FFu, ref = (u32)(d >> 26) & 0xFFu;
@@ -1341,15 +1350,14 @@ struct glp_session {
         while ((1u << qdb) < qdf) qdb++;
         const u32 Rq = 1u << qdb, step = 1u << (rb - qdb);
         const u32 nchunks = npp + 1, nterms = nch + nch * nchunks + d.num_gate_constraints;
-        // alpha powers twice: whole (permutation terms) and as 22-bit limbs (gate constraints, AccHL): [3][nch * nterms] words
-        std::vector<u64> apow((size_t)3 * nch * nterms);
+        // alpha powers twice: whole (permutation terms) and as 22-bit limbs of m and m 2^32 (gate constraints, AccHL): [1 + APL_WORDS][nch * nterms] words
+        std::vector<u64> apow((size_t)(1 + APL_WORDS) * nch * nterms);
         for (u32 i = 0; i < nch; i++) {
             u64 x = 1;
             for (u32 k = 0; k < nterms; k++) {
                 const size_t e = (size_t)i * nterms + k;
                 apow[e] = x;
-                apow[(size_t)nch * nterms + 2 * e] = (x & 0x3FFFFFull) | (((x >> 22) & 0x3FFFFFull) << 32);
-                apow[(size_t)nch * nterms + 2 * e + 1] = x >> 44;
+                apl_words(x, &apow[(size_t)nch * nterms + APL_WORDS * e]);
                 x = mul(x, alphas[i]);
             }
         }
@@ -1791,7 +1799,7 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
         const bool light = g.type == GLP_GATE_CONSTANT || g.type == GLP_GATE_PUBLIC_INPUT || g.type == GLP_GATE_ARITHMETIC ||
                            g.type == GLP_GATE_BASE_SUM || g.type == GLP_GATE_RANDOM_ACCESS;
         // alpha indices and wire columns must fit the descriptor fields (10 and 8 bits); glp_circuit_create has already
-        // bounded num_constraints by ACC_MAX_TERMS = 1024
+        // bounded num_constraints by ACC3_MAX_TERMS = 512
         if (limb_gate && limb_list.size() < (size_t)(LIMB_SLOTS * LIMB_GROUPS) && d.num_wires <= 256) {
             limb_list.push_back(gi);                       // slots are assigned below, once all limb gates are known
         } else if (g.type == GLP_GATE_ARITHMETIC && cc->arith_ops == 0 && 4 * g.p0 <= d.num_routed_wires && d.quotient_degree_factor % 4 == 0 &&
@@ -1808,7 +1816,7 @@ static int build_quotient_plan(glp_ctx *c, glp_circuit *cc) {
         limb_list.clear();
     }
     if (!limb_list.empty()) {
-        // Up to four gates share a set of accumulators (one group); more gates go through the same launch group after group.  The
+        // Up to LIMB_SLOTS gates share a set of accumulators (one group); more gates go through the same launch group after group.  The
         // fewest groups that hold them (every group recomputes the range products of its columns), filled heaviest first.
         const u32 cnt = (u32)limb_list.size();
         const u32 G = (cnt + LIMB_SLOTS - 1) / LIMB_SLOTS;
@@ -1936,8 +1944,8 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         default: break;
         }
         GLP_REQUIRE(g.selector_index < d.num_selectors && g.group_start <= g.row && g.row < g.group_end, "bad selector data for gate %u", i);
-        GLP_REQUIRE(g.num_constraints <= ACC_MAX_TERMS, "gate %u: %u constraints exceed the %u the quotient accumulators hold", i,
-                    g.num_constraints, ACC_MAX_TERMS);
+        GLP_REQUIRE(g.num_constraints <= ACC3_MAX_TERMS, "gate %u: %u constraints exceed the %u the quotient accumulators hold", i,
+                    g.num_constraints, ACC3_MAX_TERMS);
         maxc = std::max(maxc, g.num_constraints);
     }
     GLP_REQUIRE(maxc <= d.num_gate_constraints, "num_gate_constraints smaller than a gate's constraint count");

@@ -34,10 +34,10 @@ struct glp_circuit {
     u64 *dev_sigmas = nullptr;     // [nr][n] values on H (natural order), for the partial products
     u64 *dev_consts = nullptr;     // [nc][n] values on H (selectors first): which gate sits on a row (witness.hip)
     // quotient launch plan (built once in glp_circuit_create): which gates share a launch
-    u64 *dev_limb_desc = nullptr;  // [group][num_wires][4] column programs of k_quotient_limbs
-    // limb gates in groups of up to 4 (one set of accumulators in registers per group; the kernel walks the groups in turn):
-    // limb_count = gates over all groups, group g holds gates limb_gi[4 g .. 4 g + limb_gcount[g])
-    u32 limb_count = 0, limb_groups = 0, limb_gcount[4] = {0, 0, 0, 0}, limb_gi[16] = {0}, limb_jlo[4] = {0, 0, 0, 0}, limb_jhi[4] = {0, 0, 0, 0};
+    u64 *dev_limb_desc = nullptr;  // [group][num_wires][LIMB_SLOTS] column programs of k_quotient_limbs
+    // limb gates in groups of up to LIMB_SLOTS = 5 (one set of accumulators in registers per group; the kernel walks the groups in turn):
+    // limb_count = gates over all groups, group g holds gates limb_gi[5 g .. 5 g + limb_gcount[g])
+    u32 limb_count = 0, limb_groups = 0, limb_gcount[4] = {0, 0, 0, 0}, limb_gi[20] = {0}, limb_jlo[4] = {0, 0, 0, 0}, limb_jhi[4] = {0, 0, 0, 0};
     u32 limb_extra_count = 0, limb_extra_gi[4] = {0, 0, 0, 0};
     u32 arith_gi = 0, arith_ops = 0;   // ArithmeticGate evaluated inside the permutation loop (0 ops: none)
     u32 light_count = 0, light_gi[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -66,3 +66,39 @@ def test_two_signatures_batch_circuit(ctx, oracle):
     oc = oracle.OracleCircuit(c, cs_cap=gc.constants_sigmas_cap())
     assert oc.verify(proof) == 0
     gc.free()
+
+
+@pytest.mark.parametrize("which", ["fixed_base", "glv", "msm"])
+def test_scalar_multiplication_gadgets(ctx, oracle, which):
+    """The three scalar-multiplication circuits the verification is made of, each as the reference tests it on its own:
+    `test_fixed_base` [REF src/ecdsa/gadgets/curve_fixed_base.rs:88-117], `test_glv_gadget` [REF src/ecdsa/gadgets/glv.rs:195-224],
+    `test_curve_msm` [REF src/ecdsa/gadgets/curve_msm.rs:98-137] (full 256-bit scalars there: four 2-bit windows per limb)."""
+    rng = np.random.default_rng({"fixed_base": 1, "glv": 2, "msm": 3}[which])
+    rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (E.FN - 1) + 1
+    eb = E.EcdsaBuilder()
+    if which == "fixed_base":
+        n = rnd()
+        got = eb.fixed_base_curve_mul(E.G, eb.virtual_nonnative(n))
+        want = E.pt_mul(n, E.G)
+    elif which == "glv":
+        p, k = E.pt_mul(rnd(), E.G), rnd()
+        got = eb.glv_mul(eb.constant_affine_point(p), eb.constant_biguint(k) + [eb.zero_u32()] * (8 - len(E._u32_digits(k))))
+        want = E.pt_mul(k, p)
+    else:
+        p, q, n, m = E.pt_mul(rnd(), E.G), E.pt_mul(rnd(), E.G), rnd(), rnd()
+        got = eb.curve_msm(eb.constant_affine_point(p), eb.constant_affine_point(q), eb.virtual_nonnative(n), eb.virtual_nonnative(m))
+        want = E.pt_add(E.pt_mul(n, p), E.pt_mul(m, q))
+    assert eb.point_value(got) == want
+    eb.curve_assert_valid(got)
+    expected = eb.constant_affine_point(want)
+    eb.connect_biguint(got[0], expected[0]); eb.connect_biguint(got[1], expected[1])
+    c = eb.build()
+    gc = glp.Circuit(ctx, c)
+    proof = gc.prove()
+    assert gc.verify(proof)
+    oc = oracle.OracleCircuit(c, cs_cap=gc.constants_sigmas_cap())
+    assert oc.verify(proof) == 0
+    bad = proof.copy()
+    bad[7] ^= np.uint64(1)
+    assert not gc.verify(bad)
+    gc.free()

@@ -75,8 +75,9 @@ class GadgetBuilder:
     def __init__(self, config=None):
         self.cfg = config or synth.Config.standard_recursion_config()
         nw, nr = self.cfg.num_wires, self.cfg.num_routed_wires
-        self.val, self._parent = [], []
-        self._cell_t, self._cell_r, self._cell_c = [], [], []      # every routed cell: (target, row, column)
+        from array import array
+        self.val, self._parent = array("Q"), array("q")             # 8-byte arrays, not lists of Python ints: a 2^20-row circuit has 6.5 M targets
+        self._cell_t, self._cell_r, self._cell_c = array("q"), array("q"), array("q")      # every routed cell: (target, row, column)
         self.rows = []                 # per row: [gate type, p0, p1, (const0, const1)]
         self._open = {}                # slot key -> [row, next free op]
         self._ops = {t: [] for t in (GATE_U32_ARITHMETIC, GATE_U32_SUBTRACTION, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_U32,
@@ -369,14 +370,14 @@ class GadgetBuilder:
         for (g, p0, p1), rr in by_kind.items():
             b.set_rows(np.array(rr), g, p0, p1)
         # routed cells of every target; one sigma cycle per connected class (all in numpy: a 2^20-row circuit has ~10^7 cells)
-        ct = np.array(self._cell_t, dtype=np.int64)
-        cr = np.array(self._cell_r, dtype=np.int64)
-        cc = np.array(self._cell_c, dtype=np.int64)
+        ct = np.frombuffer(self._cell_t, dtype=np.int64)
+        cr = np.frombuffer(self._cell_r, dtype=np.int64)
+        cc = np.frombuffer(self._cell_c, dtype=np.int64)
         flat = cr * cfg.num_routed_wires + cc
         assert len(np.unique(flat)) == len(flat), "a routed cell was assigned twice"
-        vals = np.array(self.val, dtype=np.uint64)
+        vals = np.frombuffer(self.val, dtype=np.uint64)
         b.wires[cc, cr] = vals[ct]
-        par = np.array(self._parent, dtype=np.int64)
+        par = np.frombuffer(self._parent, dtype=np.int64).copy()
         while True:                                           # pointer jumping: every target -> the root of its class
             nxt = par[par]
             if (nxt == par).all():

@@ -321,6 +321,7 @@ __global__ void k_keccak256(const uint8_t *msgs, size_t count, size_t len, uint8
 }
 extern "C" int glp_keccak256(glp_ctx *c, const uint8_t *msgs, size_t count, size_t len, uint8_t *digests_out) {
     GLP_REQUIRE(c && digests_out && (msgs || !len), "null argument");
+    GLP_REQUIRE(len == 0 || count <= ((size_t)1 << 40) / len, "count * len = %zu * %zu bytes is more than this entry point stages (2^40)", count, len);
     GLP_TRY(bind(c));
     if (!count) return GLP_OK;
     Scratch s(c);

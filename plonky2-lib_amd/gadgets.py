@@ -231,6 +231,7 @@ class GadgetBuilder:
     def uninterleave_to_b32(self, x): return self._uninterleave(GATE_UNINTERLEAVE_B32, "ulb32", x)     # [REF :118-132]
 
     def and_xor_b32(self, x, y): return self.uninterleave_to_b32(self.add(x, y))                        # [REF :183-186]
+    def and_xor_u32(self, x, y): return self.and_xor_b32(self.interleave_u32(x), self.interleave_u32(y))   # [REF :188-192]
     def and_xor_b32_to_u32(self, x, y): return self.uninterleave_to_u32(self.add(x, y))                 # [REF :194-197]
     def and_xor_u32_to_u32(self, x, y): return self.and_xor_b32_to_u32(self.interleave_u32(x), self.interleave_u32(y))
     def and_u32(self, x, y): return self.and_xor_u32_to_u32(x, y)[0]

@@ -81,3 +81,14 @@ def test_keccak256_long_circuit(ctx, oracle, hasher):
     p2 = gc.prove(wires=s.wires, public_inputs=s.public_inputs)
     assert _pi_hex(p2) == SHORT[2][1] and gc.verify(p2)
     gc.free()
+
+
+def test_b32_gadget_circuit(ctx, oracle):
+    """BASELINE config 1 (the u32 / b32 gadget circuit, tests/test_keccak_circuit.py::b32_gadget_circuit) on the GPU: word-equal to the checker's proof"""
+    from test_keccak_circuit import b32_gadget_circuit
+    c = b32_gadget_circuit(seed=9)
+    gc, oc = glp.Circuit(ctx, c), oracle.OracleCircuit(c)
+    proof = gc.prove()
+    rc, ref = oc.prove()
+    assert rc == 0 and (proof == ref).all() and gc.verify(proof) and oc.verify(proof) == 0
+    gc.free()

@@ -97,3 +97,58 @@ def test_four_block_circuit_long_vector():
     assert d.gates == c.gates and (d.sigmas == c.sigmas).all() and (d.constants == c.constants).all()
     with pytest.raises(ValueError):
         gadgets.keccak256_circuit(msg, blocks_num=3)
+
+
+def b32_gadget_circuit(seed=5):
+    """BASELINE config 1: every method of the reference's `CircuitBuilderB32` [REF src/u32/interleaved_u32.rs:19-54] on random u32 / u64
+    inputs in one circuit, each result checked against Python integers while wiring."""
+    rng = np.random.default_rng(seed)
+    gb = gadgets.GadgetBuilder()
+    M = (1 << 32) - 1
+    r32 = lambda: int(rng.integers(0, 1 << 32))
+    rot = lambda v, n, w: ((v << n) | (v >> (w - n))) & ((1 << w) - 1) if n % w else v
+    x, y, z = r32(), r32(), r32()
+    X, Y, Z = gb.target(x), gb.target(y), gb.target(z)
+    v = gb.val
+    assert v[gb.not_u32(X)] == x ^ M
+    assert v[gb.xor_u32(X, Y)] == x ^ y and v[gb.and_u32(X, Y)] == x & y
+    for n in (1, 7, 13, 31):
+        assert v[gb.lsh_u32(X, n)] == (x << n) & M and v[gb.rsh_u32(X, n)] == x >> n
+        assert v[gb.lrot_u32(X, n)] == rot(x, n, 32) and v[gb.rrot_u32(X, n)] == rot(x, 32 - n, 32)
+    assert v[gb.rsh_u32(X, 0)] == x
+    for bit in (0, 1):
+        assert v[gb.conditional_u32(X, Y, gb.target(bit))] == (x if bit else y)
+    a, b = gb.and_xor_u32(X, Y)
+    assert v[a] == gadgets._interleave(x & y) and v[b] == gadgets._interleave(x ^ y)
+    for k in range(0, 8):                                     # unsafe_xor_many_u32: every branch of its case split
+        vals = [r32() for _ in range(k)]
+        want = 0
+        for t in vals:
+            want ^= t
+        assert v[gb.unsafe_xor_many_u32([gb.target(t) for t in vals])] == want
+    lo, hi = r32(), r32()
+    w64 = lo | (hi << 32)
+    W = [gb.target(lo), gb.target(hi)]
+    for n in (1, 31, 33, 44, 62):
+        out = gb.lrot_u64(W, n)
+        assert v[out[0]] | (v[out[1]] << 32) == rot(w64, n, 64)
+    o = gb.not_u64(W)
+    assert v[o[0]] | (v[o[1]] << 32) == w64 ^ ((1 << 64) - 1)
+    V = [gb.target(y), gb.target(z)]
+    o = gb.xor_u64(W, V)
+    assert v[o[0]] == lo ^ y and v[o[1]] == hi ^ z
+    o = gb.and_u64(W, V)
+    assert v[o[0]] == lo & y and v[o[1]] == hi & z
+    o = gb.conditional_u64(W, V, gb.target(1))
+    assert (v[o[0]], v[o[1]]) == (lo, hi)
+    for t in (a, b, o[0]):
+        gb.register_public_input(t)
+    return gb.build()
+
+
+def test_b32_gadgets(oracle):
+    c = b32_gadget_circuit()
+    assert len(c.public_inputs) == 3
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0 and oc.verify(proof) == 0

@@ -392,7 +392,8 @@ def main():
         t_build = time.perf_counter()
         desc = gadgets_ecdsa.ecdsa_circuit(gadgets_ecdsa.random_signatures(nsig, seed=SEED + 1000 * rank), min_log_n=lg)
         t_build = time.perf_counter() - t_build
-        assert desc.degree_bits == lg
+        if desc.degree_bits != lg:
+            raise SystemExit("bench.py: %d signatures gave 2^%d rows, expected 2^%d" % (nsig, desc.degree_bits, lg))
     else:
         desc = synth.ecdsa_shape_circuit(lg, seed=SEED + 1000 * rank)
     circuit = glp.Circuit(ctx, desc)

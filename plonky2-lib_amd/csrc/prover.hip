@@ -499,8 +499,15 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
         case GLP_GATE_U32_ADD_MANY: {
             u32 k = 0; const u32 na = g.p0, nops = g.p1, wd = na + 3;
             for (u32 i = 0; i < nops; i++) {
-                u64 sum = W[(size_t)(wd * i + na) * N];
-                for (u32 j = 0; j < na; j++) sum = add(sum, W[(size_t)(wd * i + j) * N]);
+                // addends + carry in as a 96-bit integer sum (three carry instructions per term against a modular addition's eight), folded once
+                u64 slo = W[(size_t)(wd * i + na) * N];
+                u32 shi = 0;
+                for (u32 j = 0; j < na; j += 8) {          // eight loads in flight (na is a run-time value: no unrolling otherwise)
+                    u64 t[8];
+                    _Pragma("unroll") for (u32 e = 0; e < 8; e++) t[e] = j + e < na ? W[(size_t)(wd * i + j + e) * N] : 0;
+                    _Pragma("unroll") for (u32 e = 0; e < 8; e++) { slo += t[e]; shi += slo < t[e] ? 1u : 0u; }
+                }
+                const u64 sum = canon(fold96_nc(slo, shi));
                 const u64 res = W[(size_t)(wd * i + na + 1) * N], car = W[(size_t)(wd * i + na + 2) * N];
                 EMIT(k, sub(add(mul(car, (u64)1 << 32), res), sum)); k++;
                 if constexpr (!HEAD_ONLY) {

@@ -605,12 +605,13 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
             for (u32 cpy = 0; cpy < copies; cpy++) {
                 const u64 *bse = W + (size_t)((2 + vs) * cpy) * N, *bw = W + (size_t)(routed + bits * cpy) * N;
                 u64 idx = 0;
-                for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; EMIT(k, mul_nc(bit, sub(bit, 1))); k++; }
-                for (int b = (int)bits - 1; b >= 0; b--) idx = add(dbl(idx), bw[(size_t)b * N]);
-                EMIT(k, sub(idx, bse[0])); k++;
                 u64 sel;
-                if (bits == 4) {           // the width the reference uses; folded in registers
-                    const u64 b0 = bw[0], b1 = bw[N], b2 = bw[2 * N], b3 = bw[3 * N];
+                if (bits == 4) {           // the width the reference uses; folded in registers, every wire loaded once and the loads batched
+                    const u64 b0 = bw[0], b1 = bw[N], b2 = bw[2 * N], b3 = bw[3 * N], claimed_idx = bse[0];
+                    EMIT(k, mul_nc(b0, sub(b0, 1))); EMIT(k + 1, mul_nc(b1, sub(b1, 1))); EMIT(k + 2, mul_nc(b2, sub(b2, 1))); EMIT(k + 3, mul_nc(b3, sub(b3, 1)));
+                    k += 4;
+                    idx = add(dbl(add(dbl(add(dbl(b3), b2)), b1)), b0);
+                    EMIT(k, sub(idx, claimed_idx)); k++;
                     u64 l2[4];
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) {
@@ -622,6 +623,9 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
                     const u64 g0 = add(l2[0], mul(b2, sub(l2[1], l2[0]))), g1 = add(l2[2], mul(b2, sub(l2[3], l2[2])));
                     sel = add(g0, mul(b3, sub(g1, g0)));
                 } else {                   // generic width: select by recursion over the index bits (no local array)
+                    for (u32 b = 0; b < bits; b++) { const u64 bit = bw[(size_t)b * N]; EMIT(k, mul_nc(bit, sub(bit, 1))); k++; }
+                    for (int b = (int)bits - 1; b >= 0; b--) idx = add(dbl(idx), bw[(size_t)b * N]);
+                    EMIT(k, sub(idx, bse[0])); k++;
                     sel = 0;
                     for (u32 j = 0; j < vs; j++) {
                         u64 ind = 1;       // product over bits of (bit or 1 - bit): Lagrange indicator of slot j

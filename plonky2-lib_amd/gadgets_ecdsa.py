@@ -415,6 +415,66 @@ class EcdsaBuilder(GadgetBuilder):
         ys = [self.random_access(index, [limb(p[1], i) for p in pts]) for i in range(8)]
         return (xs, ys)
 
+    # ---- the two general scalar multiplications the reference also defines (not on the ECDSA path, which uses fixed-base + GLV/MSM)
+    def split_nonnative_to_bits(self, x):
+        """[REF src/ecdsa/gadgets/nonnative.rs:420-436]: `split_le_base::<2>(limb, 32)` per limb"""
+        out = []
+        for limb in x:
+            self.rows.append([GATE_BASE_SUM, 32, 2, (0, 0)])
+            row = len(self.rows) - 1
+            self.stats[GATE_BASE_SUM] = self.stats.get(GATE_BASE_SUM, 0) + 1
+            self._place(limb, row, 0)
+            v = self.val[limb]
+            out += [self._wire(row, 1 + i, (v >> i) & 1) for i in range(32)]
+        return out
+
+    def curve_scalar_mul(self, p, n, rando=None):
+        """bit-by-bit double-and-add [REF src/ecdsa/gadgets/curve.rs:211-251]; `rando`: the blinding point (random in the reference)"""
+        bits = self.split_nonnative_to_bits(n)
+        rando = rando or rando_point()
+        randot = self.constant_affine_point(rando)
+        result = self.virtual_affine_point(rando)
+        self.connect_biguint(randot[0], result[0]); self.connect_biguint(randot[1], result[1])
+        two_i_p = self.virtual_affine_point(self.point_value(p))
+        self.connect_biguint(p[0], two_i_p[0]); self.connect_biguint(p[1], two_i_p[1])
+        for bit in bits:
+            not_bit = self.not_(bit)
+            s = self.curve_add(result, two_i_p)
+            x = self.add_nonnative(self.mul_biguint_by_bool(s[0], bit), self.mul_biguint_by_bool(result[0], not_bit), FP)
+            y = self.add_nonnative(self.mul_biguint_by_bool(s[1], bit), self.mul_biguint_by_bool(result[1], not_bit), FP)
+            result = (x, y)
+            two_i_p = self.curve_double(two_i_p)
+        return self.curve_add(result, self.curve_neg(randot))
+
+    def precompute_window(self, p, g=None):
+        """[REF src/ecdsa/gadgets/curve_windowed_mul.rs:50-71]: multiples[i] = i p (+ a blinding point g, removed again), i < 16"""
+        g = g or pt_mul(0x1234567, G)
+        neg = self.constant_affine_point(pt_neg(g))
+        multiples = [self.constant_affine_point(g)]
+        for i in range(1, 16):
+            multiples.append(self.curve_add(p, multiples[i - 1]))
+        for i in range(1, 16):
+            multiples[i] = self.curve_add(neg, multiples[i])
+        return multiples
+
+    def curve_scalar_mul_windowed(self, p, n):
+        """4-bit windowed multiplication [REF src/ecdsa/gadgets/curve_windowed_mul.rs:133-177]; the starting point comes from
+        KeccakHash<25>::hash_no_pad(&[0]) there"""
+        start = pt_mul(int.from_bytes(keccak256(b"\0" * 8)[:25], "little") % FN, G)
+        start_multiplied = start
+        for _ in range(256):
+            start_multiplied = pt_add(start_multiplied, start_multiplied)
+        result = self.constant_affine_point(start)
+        pre = self.precompute_window(p)
+        zero = self.zero()
+        windows = self.split_nonnative_to_4_bit_limbs(n)
+        for w in reversed(windows):
+            result = self.curve_repeated_double(result, 4)
+            to_add = self.random_access_curve_points(w, pre)
+            should_add = self.not_(self.is_equal(w, zero))
+            result = self.curve_conditional_add(result, to_add, should_add)
+        return self.curve_add(result, self.curve_neg(self.constant_affine_point(start_multiplied)))
+
     # ---- curve_fixed_base.rs
     def fixed_base_curve_mul(self, base, scalar):
         limbs = self.split_nonnative_to_4_bit_limbs(scalar)

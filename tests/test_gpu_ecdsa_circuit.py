@@ -68,12 +68,12 @@ def test_two_signatures_batch_circuit(ctx, oracle):
     gc.free()
 
 
-@pytest.mark.parametrize("which", ["fixed_base", "glv", "msm"])
+@pytest.mark.parametrize("which", ["fixed_base", "glv", "msm", "bitwise", "windowed"])
 def test_scalar_multiplication_gadgets(ctx, oracle, which):
     """The three scalar-multiplication circuits the verification is made of, each as the reference tests it on its own:
     `test_fixed_base` [REF src/ecdsa/gadgets/curve_fixed_base.rs:88-117], `test_glv_gadget` [REF src/ecdsa/gadgets/glv.rs:195-224],
     `test_curve_msm` [REF src/ecdsa/gadgets/curve_msm.rs:98-137] (full 256-bit scalars there: four 2-bit windows per limb)."""
-    rng = np.random.default_rng({"fixed_base": 1, "glv": 2, "msm": 3}[which])
+    rng = np.random.default_rng({"fixed_base": 1, "glv": 2, "msm": 3, "bitwise": 4, "windowed": 5}[which])
     rnd = lambda: int.from_bytes(rng.bytes(40), "little") % (E.FN - 1) + 1
     eb = E.EcdsaBuilder()
     if which == "fixed_base":
@@ -84,6 +84,13 @@ def test_scalar_multiplication_gadgets(ctx, oracle, which):
         p, k = E.pt_mul(rnd(), E.G), rnd()
         got = eb.glv_mul(eb.constant_affine_point(p), eb.constant_biguint(k) + [eb.zero_u32()] * (8 - len(E._u32_digits(k))))
         want = E.pt_mul(k, p)
+    elif which in ("bitwise", "windowed"):
+        # `curve_scalar_mul` [REF src/ecdsa/gadgets/curve.rs:211-251, test_curve_mul :335-363] (BaseSumGate<2> bit splits, 2^18 rows) and
+        # `curve_scalar_mul_windowed` [REF src/ecdsa/gadgets/curve_windowed_mul.rs:133-177, test :222-254]: not on the ECDSA path
+        p, n = E.pt_mul(rnd(), E.G), rnd()
+        mul = eb.curve_scalar_mul if which == "bitwise" else eb.curve_scalar_mul_windowed
+        got = mul(eb.constant_affine_point(p), eb.virtual_nonnative(n))
+        want = E.pt_mul(n, p)
     else:
         p, q, n, m = E.pt_mul(rnd(), E.G), E.pt_mul(rnd(), E.G), rnd(), rnd()
         got = eb.curve_msm(eb.constant_affine_point(p), eb.constant_affine_point(q), eb.virtual_nonnative(n), eb.virtual_nonnative(m))

@@ -706,3 +706,143 @@ def smt_inclusion_circuit(tree, key, n_levels=16, enabled=True, config=None, pub
     c.smt_witness = w
     c.computed_root = tuple(gb.val[t] for t in levels[0])
     return c
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Sparse Merkle tree PROCESS proof (insert / update / remove / no-op) [REF src/smt/gadgets/process/process_smt.rs, process/utils.rs]
+def smt_set(tree, key, value):
+    """`SparseMerkleTree::set` [REF src/smt/tree.rs:139-150,561-586]: value 0 removes (or is a no-op), otherwise updates or inserts.
+    Returns the process proof [REF src/smt/proof/process.rs] and leaves the tree in its new state.  Removal rebuilds the (canonical) tree
+    from its remaining entries instead of restating `remove` [REF src/smt/tree.rs:373-534]; the proof fields are the same."""
+    key, value = tuple(key), tuple(value)
+    items = getattr(tree, "items", None)
+    if items is None:
+        items = tree.items = {n[1]: n[2] for n in tree.nodes.values() if n[0] == "leaf" and tree.find(n[1])["found"]}
+    f = tree.find(key)
+    old_root = tree.root
+    trim = lambda sib: sib[:max((i + 1 for i, s in enumerate(sib) if s != ZERO_HASH), default=0)]
+    if value == ZERO_HASH:
+        if not f["found"]:                                   # ProcessNoOp
+            return dict(old_root=old_root, new_root=old_root, old_key=key, old_value=ZERO_HASH, new_key=key, new_value=ZERO_HASH, siblings=[],
+                        is_old0=True, fnc=(0, 0))
+        del items[key]
+        after = SparseMerkleTree()
+        for k, v in items.items():
+            after.insert(k, v)
+        g = after.find(key)                                  # the insertion of (key, old value) into `after`, read backwards
+        tree.nodes, tree.root = after.nodes, after.root
+        return dict(old_root=old_root, new_root=after.root, old_key=key, old_value=f["value"], new_key=g["not_found_key"],
+                    new_value=g["not_found_value"], siblings=trim(g["siblings"]), is_old0=g["is_old0"], fnc=(1, 1))
+    if f["found"]:                                           # ProcessUpdate: the same path, another leaf
+        items[key] = value
+        bits = _key_bits(key)
+        cur = tree._put(("leaf", key, value))
+        for lvl in range(len(f["siblings"]) - 1, -1, -1):
+            s = f["siblings"][lvl]
+            cur = tree._put(("int", s, cur) if bits[lvl] else ("int", cur, s))
+        tree.root = cur
+        return dict(old_root=old_root, new_root=cur, old_key=key, old_value=f["value"], new_key=key, new_value=value, siblings=f["siblings"],
+                    is_old0=False, fnc=(0, 1))
+    items[key] = value                                       # ProcessInsert
+    tree.insert(key, value)
+    return dict(old_root=old_root, new_root=tree.root, old_key=f["not_found_key"], old_value=f["not_found_value"], new_key=key, new_value=value,
+                siblings=trim(f["siblings"]), is_old0=f["is_old0"], fnc=(1, 0))
+
+
+def _logical_or(gb, x, y): return gb.add(_logical_and_not(gb, x, y), y)                       # [REF src/smt/gadgets/common.rs:224-237]
+def _logical_nor(gb, x, y): return _logical_and_not(gb, gb.not_(x), y)                        # [REF :250-259]
+def _logical_xor(gb, x, y): return gb.sub(x, gb.arithmetic(2, P - 1, x, y, y))                # [REF :296-311]
+def _conditionally_select(gb, x, y, cond): return _conditionally_reverse(gb, x, y, cond)[1]   # cond ? x : y   [REF :115-126]
+def _element_wise_add(gb, x, y): return [gb.arithmetic(1, 1, a, gb.one(), b) for a, b in zip(x, y)]      # [REF :178-186]
+
+
+def _enforce_equal_if_enabled(gb, left, right, enabled):                                      # [REF :347-357]
+    gb.connect(_logical_and_not(gb, enabled, _is_equal_hash_out(gb, left, right)), gb.constant_bool(False))
+
+
+def _process_role(gb, fnc):                                                                   # [REF src/smt/gadgets/process/utils.rs:28-57]
+    return dict(is_no_op=_logical_nor(gb, fnc[0], fnc[1]), is_remove_op=gb.and_(fnc[0], fnc[1]), is_insert_or_remove_op=fnc[0],
+                is_update_or_no_op=gb.not_(fnc[0]), is_not_no_op=_logical_or(gb, fnc[0], fnc[1]))
+
+
+def _smt_processor_sm(gb, xor, is0, lev_ins, is_ins_or_rem, prev):                           # [REF src/smt/gadgets/process/process_smt.rs:386-431]
+    aux1 = gb.and_(prev["top"], lev_ins)
+    aux2 = gb.and_(aux1, is_ins_or_rem)
+    top = _logical_and_not(gb, prev["top"], lev_ins)
+    old0 = gb.and_(aux2, is0)
+    t = _logical_or(gb, _logical_and_not(gb, aux2, is0), prev["bot"])
+    new1 = gb.and_(t, xor)
+    bot = _logical_and_not(gb, t, xor)
+    upd = _logical_and_not(gb, aux1, is_ins_or_rem)
+    na = _logical_or(gb, _logical_or(gb, _logical_or(gb, prev["new1"], prev["old0"]), prev["na"]), prev["upd"])
+    return dict(top=top, old0=old0, new1=new1, bot=bot, na=na, upd=upd)
+
+
+def _smt_processor_level(gb, st, sibling, old1_leaf, new1_leaf, new_lr_bit, old_child, new_child):      # [REF :292-384]
+    zero4 = [gb.zero()] * 4
+    old_hash = _calc_internal_hash(gb, old_child, sibling, new_lr_bit)
+    b_n_u = gb.add(gb.add(st["bot"], st["new1"]), st["upd"])
+    old_root = _element_wise_add(gb, _conditionally_select(gb, old_hash, zero4, st["top"]), _conditionally_select(gb, old1_leaf, zero4, b_n_u))
+    t_b = gb.add(st["top"], st["bot"])
+    new_left = _element_wise_add(gb, _conditionally_select(gb, new1_leaf, zero4, st["new1"]), _conditionally_select(gb, new_child, zero4, t_b))
+    new_right = _element_wise_add(gb, _conditionally_select(gb, old1_leaf, zero4, st["new1"]), _conditionally_select(gb, sibling, zero4, st["top"]))
+    new_hash = _calc_internal_hash(gb, new_left, new_right, new_lr_bit)
+    t_b_n = gb.add(t_b, st["new1"])
+    o_u = gb.add(st["old0"], st["upd"])
+    new_root = _element_wise_add(gb, _conditionally_select(gb, new1_leaf, zero4, o_u), _conditionally_select(gb, new_hash, zero4, t_b_n))
+    return old_root, new_root
+
+
+def smt_process_circuit(proof, n_levels=16, config=None, public=True, min_log_n=0):
+    """`SparseMerkleProcessProofTarget::add_virtual_to` + `set_witness(proof)` [REF src/smt/gadgets/process/process_smt.rs:41-118,120-290;
+    driver: src/smt/gadgets/process/mod.rs:4-82, which registers keys, values and roots as public inputs].  `proof` = `smt_set(...)`."""
+    if len(proof["siblings"]) >= n_levels:
+        raise ValueError("siblings are too long")
+    gb = GadgetBuilder(config)
+    h4 = lambda v: [gb.target(x) for x in v]
+    siblings = [h4(s) for s in proof["siblings"]] + [h4(ZERO_HASH) for _ in range(n_levels - len(proof["siblings"]))]
+    old_root, old_key, old_value = h4(proof["old_root"]), h4(proof["old_key"]), h4(proof["old_value"])
+    new_root, new_key, new_value = h4(proof["new_root"]), h4(proof["new_key"]), h4(proof["new_value"])
+    is_old0 = gb.add_virtual_bool_target_safe(proof["is_old0"])
+    fnc = [gb.add_virtual_bool_target_safe(proof["fnc"][0]), gb.add_virtual_bool_target_safe(proof["fnc"][1])]
+    pis = old_key + old_value + new_key + new_value + old_root + new_root
+    # verify_smt_process_proof
+    true_t, false_t = gb.constant_bool(True), gb.constant_bool(False)
+    zero4 = [gb.zero()] * 4
+    is_remove = _process_role(gb, fnc)["is_remove_op"]
+    # a removal is checked as the insertion it undoes: swap old and new, clear fnc[1]      [REF :144-158]
+    tmp = gb.mul_sub(is_remove, fnc[1], fnc[1])
+    fnc = [fnc[0], gb.mul_sub(is_remove, false_t, tmp)]                                    # builder._if(is_remove, false, fnc[1])
+    old_key, new_key = _conditionally_reverse(gb, old_key, new_key, is_remove)
+    old_value, new_value = _conditionally_reverse(gb, old_value, new_value, is_remove)
+    old_root, new_root = _conditionally_reverse(gb, old_root, new_root, is_remove)
+    role = _process_role(gb, fnc)
+    enabled = role["is_not_no_op"]
+    gb.connect(role["is_remove_op"], false_t)
+    hash1_old = _calc_leaf_hash(gb, old_key, old_value)
+    hash1_new = _calc_leaf_hash(gb, new_key, new_value)
+    n2b_old = [b for e in old_key for b in gb.split_le(e, 64)]
+    n2b_new = [b for e in new_key for b in gb.split_le(e, 64)]
+    lev_ins = _smt_lev_ins(gb, enabled, siblings)
+    xors = [_logical_xor(gb, a, b) for a, b in zip(n2b_old[:n_levels], n2b_new[:n_levels])]
+    prev = dict(top=enabled, old0=false_t, new1=false_t, bot=false_t, na=gb.not_(enabled), upd=false_t)
+    sm = []
+    for i in range(n_levels):
+        prev = _smt_processor_sm(gb, xors[i], is_old0, lev_ins[i], role["is_insert_or_remove_op"], prev)
+        sm.append(prev)
+    last = sm[-1]
+    gb.connect(_logical_or(gb, _logical_or(gb, last["na"], last["new1"]), _logical_or(gb, last["old0"], last["upd"])), true_t)
+    level = (zero4, zero4)
+    for i in range(n_levels - 1, -1, -1):
+        level = _smt_processor_level(gb, sm[i], siblings[i], hash1_old, hash1_new, n2b_new[i], level[0], level[1])
+    _enforce_equal_if_enabled(gb, level[0], old_root, enabled)
+    _enforce_equal_if_enabled(gb, level[1], new_root, enabled)
+    _enforce_equal_if_enabled(gb, old_key, new_key, role["is_update_or_no_op"])
+    _enforce_equal_if_enabled(gb, old_root, new_root, role["is_no_op"])
+    _enforce_equal_if_enabled(gb, old_value, new_value, role["is_no_op"])
+    if public:
+        for t in pis:
+            gb.register_public_input(t)
+    c = gb.build(min_log_n)
+    c.computed_roots = (tuple(gb.val[t] for t in level[0]), tuple(gb.val[t] for t in level[1]))
+    return c

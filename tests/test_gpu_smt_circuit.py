@@ -77,3 +77,19 @@ def test_many_inclusion_proofs_of_a_larger_tree(ctx, oracle):
     bad[-8:] = proofs[1][-8:]
     assert not gc.verify(bad)
     gc.free()
+
+
+def test_process_proofs_on_the_gpu(ctx, oracle):
+    """`test_verify_process_proof_by_plonky2` [REF src/smt/gadgets/process/mod.rs:4-82]: insert / update / remove / no-op witnesses of ONE circuit in one
+    lock-step batch, each word-equal to the single proof, the first also to the checker's"""
+    from test_smt_circuit import process_sequence
+    seq = list(process_sequence())
+    c0 = seq[0][2]
+    gc, oc = glp.Circuit(ctx, c0), oracle.OracleCircuit(c0)
+    batch = gc.prove_batch(np.stack([c.wires for _, _, c in seq]), np.stack([c.public_inputs for _, _, c in seq]))
+    for (name, proof, c), p in zip(seq, batch):
+        assert gc.verify(p) and oc.verify(p) == 0, name
+        assert (p == gc.prove(wires=c.wires, public_inputs=c.public_inputs)).all(), name
+    rc, ref = oc.prove()
+    assert rc == 0 and (batch[0] == ref).all()
+    gc.free()

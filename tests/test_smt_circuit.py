@@ -126,3 +126,43 @@ def test_calc_node_hash_circuit(oracle):
     oc = oracle.OracleCircuit(c)
     rc, proof = oc.prove()
     assert rc == 0 and oc.verify(proof) == 0
+
+
+# ---- the PROCESS proof (insert / update / remove / no-op) [REF src/smt/gadgets/process/process_smt.rs; driver src/smt/gadgets/process/mod.rs:4-82]
+def process_sequence():
+    """a small history touching every role; yields (name, proof, circuit)"""
+    t = G.SparseMerkleTree()
+    for name, k, v in (("insert into the empty tree", 1, 2), ("insert next to a leaf", 12, 1), ("insert below two levels", 5, 51),
+                       ("update", 12, 7), ("no-op", 99, 0), ("remove (a sibling leaf moves up)", 5, 0), ("insert", 4, 9), ("remove", 1, 0)):
+        proof = G.smt_set(t, H(k), H(v))
+        yield name, proof, G.smt_process_circuit(proof)
+
+
+def test_process_circuit_all_roles(oracle):
+    seen, first = set(), None
+    for name, proof, c in process_sequence():
+        seen.add(proof["fnc"])
+        first = first or c
+        assert c.gates == first.gates and (c.sigmas == first.sigmas).all() and (c.constants == first.constants).all(), name     # one circuit
+        if proof["fnc"] != (0, 0):            # the two hash chains computed by the gates end in the native roots (a removal is checked backwards)
+            want = (proof["new_root"], proof["old_root"]) if proof["fnc"] == (1, 1) else (proof["old_root"], proof["new_root"])
+            assert c.computed_roots == want, name
+        assert [int(x) for x in c.public_inputs] == [int(x) for part in ("old_key", "old_value", "new_key", "new_value", "old_root", "new_root")
+                                                     for x in proof[part]]
+        oc = oracle.OracleCircuit(c)
+        rc, p = oc.prove()
+        assert rc == 0 and oc.verify(p) == 0, name
+    assert seen == {(0, 0), (0, 1), (1, 0), (1, 1)}
+    assert first.degree_bits == 8 and first.gate_ops["PoseidonGate"] == 2 * 2 + 2 * 16 + 3        # two leaf hashes, two chains of 16, 24 public inputs
+
+
+def test_process_circuit_rejects_a_wrong_transition():
+    t = G.SparseMerkleTree()
+    G.smt_set(t, H(1), H(2))
+    proof = G.smt_set(t, H(12), H(1))
+    bad = dict(proof, new_root=(1, 2, 3, 4))                  # claims another root after the insertion
+    with pytest.raises(ValueError):
+        G.smt_process_circuit(bad)
+    bad = dict(proof, fnc=(0, 1))                             # an insertion presented as an update: old key != new key
+    with pytest.raises(ValueError):
+        G.smt_process_circuit(bad)

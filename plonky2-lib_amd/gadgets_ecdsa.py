@@ -293,6 +293,19 @@ class EcdsaBuilder(GadgetBuilder):
 
     def mul_biguint_by_bool(self, a, b): return [self.mul(l, b) for l in a]
 
+    def div_rem_biguint(self, a, b):
+        """[REF src/ecdsa/gadgets/biguint.rs:235-264]: quotient and remainder supplied by a generator, a = div b + rem and rem <= b enforced"""
+        va, vb = self.val_of(a), self.val_of(b)
+        div = self.virtual_biguint(va // vb, 0 if len(b) > len(a) + 1 else len(a) - len(b) + 1)
+        rem = self.virtual_biguint(va % vb, len(b))
+        self.connect_biguint(a, self.add_biguint(self.mul_biguint(div, b), rem))
+        self.connect(self.cmp_biguint(rem, b), self.one())
+        return div, rem
+
+    def reduce(self, x, m):
+        """`reduce` [REF src/ecdsa/gadgets/nonnative.rs:393-402]: x mod m through div_rem_biguint"""
+        return self.div_rem_biguint(x, self.constant_biguint(m))[1]
+
     # ---- nonnative.rs (m = the foreign modulus; values are limb lists)
     def virtual_nonnative(self, value): return self.virtual_biguint(value, 8)
 

@@ -54,6 +54,9 @@ def test_biguint_and_nonnative_gadgets(oracle):
         assert eb.val_of(eb.inv_nonnative(at, m)) == pow(a, -1, m)
         for flag in (0, 1):
             assert eb.val_of(eb.nonnative_conditional_neg(at, eb.target(flag), m)) == ((-a) % m if flag else a)
+    div, rem = eb.div_rem_biguint(eb.mul_biguint(xt, yt), eb.constant_biguint(E.FN))          # test_biguint_div_rem
+    assert eb.val_of(div) == x * y // E.FN and eb.val_of(rem) == x * y % E.FN
+    assert eb.val_of(eb.reduce(eb.add_biguint(xt, yt), E.FP)) == (x + y) % E.FP
     four = eb.split_nonnative_to_4_bit_limbs(xt)
     assert sum(eb.val[t] << (4 * i) for i, t in enumerate(four)) == x and len(four) == 64
     c = eb.build()

@@ -458,7 +458,7 @@ API int glo_prove(const glo_circuit *c, const u64 *wires /* [num_wires][n] */, c
     }
     u64 pih[4];
     glo_hash_no_pad(public_inputs, c->num_public_inputs, pih);
-    memcpy(proof + L.pis, public_inputs, (size_t)c->num_public_inputs * 8);
+    if (c->num_public_inputs) memcpy(proof + L.pis, public_inputs, (size_t)c->num_public_inputs * 8);      /* (NULL, 0) is not a valid memcpy source */
 
     obatch wb; obatch_from_values(&wb, wires, nw, c);
     memcpy(proof + L.caps, wb.cap, capn * 32);

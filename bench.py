@@ -2,13 +2,18 @@
 """bench.py -- throughput of the MI355X prove() hot path on the reference's headline workload.
 
 Workload (BASELINE.json configs[2]): the secp256k1 ECDSA-verify circuit of
-`test_batch_ecdsa_circuit_with_config(20, standard_ecc_config)` [REF src/bin/perf.rs:7-9,
-src/ecdsa/gadgets/ecdsa.rs:215-378] has a 2^20-row trace with 136 wire columns, 20 Z/partial-product
-columns and 16 quotient-chunk columns.  The circuit itself cannot be built
-here (no Rust, plonky2 fork absent), so the trace is synthetic: SplitMix64-seeded uniform field
-elements of exactly that shape, generated directly in HBM.
+`test_batch_ecdsa_circuit_with_config(.., standard_ecc_config)` [REF src/bin/perf.rs:7-9, src/ecdsa/gadgets/ecdsa.rs:215-378] on a
+2^20-row trace: 136 wire columns, 20 Z / partial-product columns, 16 quotient-chunk columns.
 
-One "step" = one complete prove() (everything after witness generation) from an HBM-resident witness.
+Default (`--circuit real`): the REAL circuit, rebuilt gadget for gadget in Python (plonky2-lib_amd/gadgets_ecdsa.py) on the host
+BEFORE the timed region, with a valid witness of random signatures.  At this repository's gate density (98 687 rows per signature;
+row count against plonky2's own builder: parity unpinned) a 2^20-row trace holds TEN signatures, not the twenty of `perf.rs`: the
+twenty-signature batch is a 2^21-row trace and is timed, verified, as `variants.perf_rs_batch_20`; `signatures_per_proof` and
+`signatures_per_sec` are top-level fields of the JSON line.  `--circuit stand-in` times the gate-mix circuit of the same shape that
+rounds 1-2 used (`variants.gate_mix_stand_in` in the default run).
+
+One "step" = one complete prove() (everything after witness generation) from an HBM-resident witness.  After the timed loop every
+rank checks its last proof with glp_verify (`"verified"`), rank 0 also with the oracle's verifier (inside `cpu_baseline`).
 Usage: python bench.py --gpus N --steps K --warmup W
   N > 1 under torch.distributed.run (RANK / WORLD_SIZE set): this process is one rank.
   N > 1 started bare: bench.py starts the N ranks itself (fresh child processes, before anything touches a GPU).
@@ -54,7 +59,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=1,
                     help="ecdsa: independent proofs proved concurrently per GPU (own context/stream/host thread each); a step is "
                          "then a batch of that many proofs.  Default 1 keeps the per-stage timings free of overlap")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra two-proofs-in-flight measurement after the timed region")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements after the timed region (host witness, two in flight, stand-in, perf.rs batch)")
+    ap.add_argument("--no-perf-rs", action="store_true", help="skip variants.perf_rs_batch_20 (a 2^21-row circuit: ~40 s of host-side circuit building)")
     ap.add_argument("--dist-backend", default=None, help="override the torch.distributed backend (rehearsals: gloo)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     return ap.parse_args()
@@ -185,6 +191,71 @@ def cpu_baseline(full_log_n, sample_log_n, gpu_proof=None, gpu_circuit_desc=None
                      "commitments (%.2f s), times 2^%d = %.1f s" % (full_log_n, t[8], t[16], commit_full, lgs, t_prove,
                                                                      t_commit_s, full_log_n - lgs, rest))
     return out
+
+
+def stage_table(raw, steps):
+    """glp_ctx_stage_get records of `steps` proofs -> ({key: [ms total, count, algorithmic bytes]}, keys in order, {key: {ms, alg_GB, GBps}} per proof)"""
+    per_step = len(raw) // max(steps, 1)
+    stages, order = {}, []
+    for idx, (name, ms, by) in enumerate(raw):
+        pos = idx % per_step
+        if pos == 0:
+            seen = {}
+        if name in BATCH_STAGES:
+            k = seen.get(name, 0)
+            seen[name] = k + 1
+            if name in ("copy_coeffs", "bitrev_coeffs"):
+                k = 2
+            key = "%s/%s" % (SHAPES[min(k, 2)][0], name)
+        else:
+            key = name
+        if key not in stages:
+            stages[key] = [0.0, 0, by]
+            order.append(key)
+        stages[key][0] += ms
+        stages[key][1] += 1
+    stage_out = {}
+    for k in order:
+        ms_avg = stages[k][0] / max(steps, 1)      # per proof (a stage may be recorded several times per proof)
+        stage_out[k] = {"ms": round(ms_avg, 4), "alg_GB": round(stages[k][2] / 1e9, 4),
+                        "GBps": round(stages[k][2] / 1e9 / (ms_avg / 1e3), 1) if ms_avg > 0 and stages[k][2] else None}
+    return stages, order, stage_out
+
+
+def perf_rs_variant(glp, ctx, torch, dev, np, nsig=20, steps=3):
+    """The literal `perf` workload [REF src/bin/perf.rs:7-9]: `test_batch_ecdsa_circuit_with_config(20, standard_ecc_config)` --
+    TWENTY signatures in one circuit.  At this repository's gate density that is a 2^21-row trace (two NTT passes, the strided one
+    on 512-row LDS tiles).  Built on the host, proved `steps` times from an HBM-resident witness with the stage timers on, the last
+    proof checked by glp_verify; outside the headline's timed region and never `value`."""
+    from plonky2_lib_amd import gadgets_ecdsa
+    t0 = time.perf_counter()
+    desc = gadgets_ecdsa.ecdsa_circuit(gadgets_ecdsa.random_signatures(nsig, seed=SEED + 20))
+    t_build = time.perf_counter() - t0
+    circuit = glp.Circuit(ctx, desc)
+    wires = torch.from_numpy(desc.wires.view(np.int64)).to(dev)
+    proof = circuit.prove_device(wires.data_ptr())                      # warm-up: plans, pool
+    ctx.set_profiling(True)
+    ctx.stage_reset()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        proof = circuit.prove_device(wires.data_ptr())
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    _, order, stage_out = stage_table(ctx.stages(), steps)
+    ctx.set_profiling(False)
+    ctx.stage_reset()
+    ok = bool(circuit.verify(proof))
+    res = {"value": 1.0 / dt, "unit": "proofs/sec", "ms_per_proof": dt * 1e3, "signatures_per_proof": nsig, "signatures_per_sec": nsig / dt,
+           "log_n": int(desc.degree_bits), "gate_rows": int(desc.gadget_rows), "verified": ok, "circuit_build_s": round(t_build, 1),
+           "stages": {k: stage_out[k] for k in order},
+           "note": "%d signatures = 2^%d rows x 136 wires at this repository's gate density (parity with plonky2's row count unpinned); "
+                   "HBM-resident witness, one proof in flight; not the headline value" % (nsig, desc.degree_bits)}
+    circuit.free()
+    del wires
+    if not ok:
+        raise SystemExit("bench.py: glp_verify REJECTED the 20-signature proof")
+    return res
 
 
 def spawn_ranks(a):
@@ -439,31 +510,7 @@ def main():
     ok_all = grp.max_over_ranks(0.0 if ok_local else 1.0) == 0.0
 
     # per-stage device times (hipEvents on the library's own stream), averaged per launch
-    raw = ctx.stages()
-    per_step = len(raw) // max(a.steps, 1)
-    stages, order = {}, []
-    for idx, (name, ms, by) in enumerate(raw):
-        pos = idx % per_step
-        if pos == 0:
-            seen = {}
-        if name in BATCH_STAGES:
-            k = seen.get(name, 0)
-            seen[name] = k + 1
-            if name in ("copy_coeffs", "bitrev_coeffs"):
-                k = 2
-            key = "%s/%s" % (SHAPES[min(k, 2)][0], name)
-        else:
-            key = name
-        if key not in stages:
-            stages[key] = [0.0, 0, by]
-            order.append(key)
-        stages[key][0] += ms
-        stages[key][1] += 1
-    stage_out = {}
-    for k in order:
-        ms_avg = stages[k][0] / max(a.steps, 1)      # per proof (a stage may be recorded several times per proof)
-        stage_out[k] = {"ms": round(ms_avg, 4), "alg_GB": round(stages[k][2] / 1e9, 4),
-                        "GBps": round(stages[k][2] / 1e9 / (ms_avg / 1e3), 1) if ms_avg > 0 and stages[k][2] else None}
+    stages, order, stage_out = stage_table(ctx.stages(), a.steps)
     dom = max(order, key=lambda k: stage_out[k]["ms"])
     ach = stage_out[dom]["GBps"]
     nm = [k for k in order if k.split("/")[-1] in ("intt", "lde", "merkle_leaves", "merkle_levels")]
@@ -490,6 +537,8 @@ def main():
             "data": "synthetic",
             "verified": ok_all,
             "verified_by": "glp_verify (CircuitData::verify restatement, host code) on the last proof of every rank's timed loop",
+            "signatures_per_proof": nsig if real else None,
+            "signatures_per_sec": (nsig * world * max(a.inflight, 1) * a.steps / dt) if real else None,
             "config": ({
                 "workload": "secp256k1 ECDSA verification circuit, %d signatures per proof: `batch_verify_message_circuit` [REF src/ecdsa/gadgets/"
                             "ecdsa.rs:161-191] rebuilt gadget for gadget (nonnative arithmetic on u32 limbs, 4-bit windowed fixed-base "
@@ -498,9 +547,11 @@ def main():
                             "17 gates in 4 selector groups: %s; one full prove() per step from an HBM-resident witness: wires commit, partial "
                             "products, quotient, openings, FRI, PoW, queries" %
                             (nsig, lg, desc.gadget_rows, ", ".join("%s x%d" % kv for kv in desc.gate_rows.items())),
-                "note": "circuit and witness built by this repository's Python restatement of the reference's gadgets (%.0f s of host time before "
+                "note": "each proof holds %d signatures, not the 20 of perf.rs [REF src/bin/perf.rs:7-9]: at this repository's gate density the "
+                        "20-signature batch is a 2^21-row trace (variants.perf_rs_batch_20); row count vs plonky2's builder: parity unpinned.  "
+                        "Circuit and witness built by this repository's Python restatement of the reference's gadgets (%.0f s of host time before "
                         "the timed region; gate placement is not plonky2's); every signature is a valid random signature, a forged one cannot be "
-                        "wired.  Rounds 1 and 2 timed a gate-mix stand-in of the same shape: variants.gate_mix_stand_in" % t_build,
+                        "wired.  Rounds 1 and 2 timed a gate-mix stand-in of the same shape: variants.gate_mix_stand_in" % (nsig, t_build),
                 "parallelism": "independent proofs sharded one per GPU, no collective",
                 "signatures_per_proof": nsig,
                 "proofs_in_flight_per_gpu": max(a.inflight, 1),
@@ -528,7 +579,9 @@ def main():
                 "unit": "GB/s",
                 "frac": (ach / HBM_PEAK_GBS) if ach else None,
                 "traffic": pmc_traffic(dom, lg),
-                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" % os.path.basename(pmc_traffic_file()),
+                "traffic_source": "COMMITTED constant, not measured in this run: profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "this same default command, bytes per launch of the dominant kernel; valid for --log-n 20 on the real circuit only, null otherwise)"
+                                  % os.path.basename(pmc_traffic_file()),
                 "algorithmic_bytes": stages[dom][2],
                 "note": "the dominant kernel (Poseidon leaf hashing) is VALU-bound, not HBM-bound: see DESIGN.md; "
                         "HBM fraction reported as the contract asks",
@@ -614,6 +667,8 @@ def main():
                             "differs in the quotient stage (17 gates instead of 11: seven U32AddMany parameter sets)"}
                 sc.free()
                 del sw
+            if real and lg == 20 and not a.no_perf_rs:
+                out["variants"]["perf_rs_batch_20"] = perf_rs_variant(glp, ctx, torch, dev, np)
         if world == 1 and not a.no_cpu_baseline:
             desc.circuit_digest = circuit.digest()
             out["cpu_baseline"] = cpu_baseline(lg, a.cpu_sample_log_n, gpu_proof=last_proof[0], gpu_circuit_desc=desc,

@@ -50,6 +50,10 @@ GLP_API const char *glp_last_error(void);
 GLP_API const char *glp_version(void);
 GLP_API int glp_device_count(void);
 
+/* Environment variables read when a context is made (tuning switches for the A/B rows under profiles/; the defaults ship):
+ *   GLP_NTT_2PASS_LG      = 20..22 (default 22): largest log2(n) transformed in two passes; above it a third pass over 2^20-point blocks
+ *   GLP_NTT_STRIDED32_LW  = 3 | 4  (default 4):  log2 columns of the 512- / 1024-row strided tile (64- or 128-byte row segments)
+ *   GLP_HOST_THREADS      (read on the first glp_prove_batch of a context): host threads for the transcripts of a batch */
 GLP_API int glp_ctx_create(int device_id, glp_ctx **out);
 GLP_API void glp_ctx_destroy(glp_ctx *ctx);
 GLP_API int glp_ctx_synchronize(glp_ctx *ctx);
@@ -241,8 +245,8 @@ GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uin
 /* Many independent proofs of ONE circuit in lock step (BASELINE config 5: a batch of zkdsa simple-signature proofs, the unit
  * [REF src/zkdsa/circuits/mod.rs:24-43,322-339] proves one at a time).  Small circuits are bound by launch and host round-trip
  * latency when proved one by one; here every device stage is one launch over all num_proofs proofs and every host round trip
- * carries all their caps / openings, while the num_proofs Fiat-Shamir transcripts run on host threads (GLP_HOST_THREADS, default:
- * the machine's cores up to 32).  proofs_out[k] is word for word what glp_prove returns for witness k.
+ * carries all their caps / openings, while the num_proofs Fiat-Shamir transcripts run on host threads (environment variable GLP_HOST_THREADS; default: the
+ * cores this process may use -- affinity mask capped by the cgroup CPU quota -- up to 32; every context has its own pool).  proofs_out[k] is word for word what glp_prove returns for witness k.
  *   wires          [num_proofs][num_wires][n], host memory, or (wires_on_device != 0) an HBM pointer on the ctx's GPU
  *   public_inputs  [num_proofs][num_public_inputs]
  *   proofs_out     [num_proofs][glp_proof_words(circuit)]

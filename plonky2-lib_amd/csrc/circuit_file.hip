@@ -13,7 +13,7 @@
 //
 // Layout (all integers little-endian; every section starts on an 8-byte boundary):
 //   0   char[8]  magic "GLPCIRC1"
-//   8   u32      version = 1
+//   8   u32      version = 2 (version 1 files -- checksum over the sections only -- are still read)
 //   12  u32      header_bytes (offset of the first section)
 //   16  u32[14]  degree_bits, num_wires, num_routed_wires, num_constants, num_selectors, num_challenges,
 //                quotient_degree_factor, num_partial_products, num_gate_constraints, rate_bits, cap_height,
@@ -24,12 +24,15 @@
 //   144 u32      has_witness (0 / 1)
 //   148 u32      hasher (GLP_HASH_POSEIDON = 0, GLP_HASH_KECCAK25 = 1; files written before the field existed hold 0)
 //   152 u64[4]   circuit_digest (all zero = derive it from the constants/sigmas cap)
-//   184 u64      checksum: FNV-1a 64 over every byte from header_bytes to the end of the file
+//   184 u64      checksum: FNV-1a 64 over header bytes [0, 184) followed by every byte from header_bytes to the end of the file
+//                (version 1: the sections only)
 //   192 = header_bytes
 //   sections, in this order: gates [num_gates] x 8 u32 (type, selector_index, group_start, group_end, row,
 //   num_constraints, p0, p1) | k_is [num_routed_wires] u64 | constants [num_constants][n] u64 | sigmas
 //   [num_routed_wires][n] u64 | (has_witness) wires [num_wires][n] u64 | (has_witness) public_inputs
 //   [num_public_inputs] u64.   n = 2^degree_bits; column-major, natural row order, canonical field elements.
+// glp_circuit_file_open checks every u64 section for values < p (the kernels assume canonical inputs: a word >= p would
+// give a silently wrong proof, and a consistent checksum does not exclude one) and names the first offender.
 #include <errno.h>
 #include <fcntl.h>
 #include <string.h>
@@ -42,7 +45,7 @@ using namespace glp;
 
 namespace {
 constexpr char MAGIC[8] = {'G', 'L', 'P', 'C', 'I', 'R', 'C', '1'};
-constexpr u32 VERSION = 1, HEADER_BYTES = 192;
+constexpr u32 VERSION = 2, HEADER_BYTES = 192, CHECKSUM_OFFSET = 184;
 
 struct Header {
     char magic[8];
@@ -115,7 +118,14 @@ int glp_circuit_file_write(const char *path, const glp_circuit_desc *d, const ui
     const void *parts[6] = {d->gates, d->k_is, d->constants, d->sigmas, wires, public_inputs};
     const size_t lens[6] = {s.gates, s.k_is, s.consts, s.sigmas, s.wires, s.pis};
     static_assert(sizeof(glp_gate) == 32, "gate record is 8 x u32");
-    u64 ck = 0xcbf29ce484222325ull;
+    // a writer is held to what the reader enforces: canonical field elements in every u64 section
+    const char *names[6] = {"gates", "k_is", "constants", "sigmas", "wires", "public_inputs"};
+    for (int i = 1; i < 6; i++) {
+        if (!lens[i]) continue;
+        const size_t bad = glp::first_noncanonical((const u64 *)parts[i], lens[i] / 8);
+        GLP_REQUIRE(bad == lens[i] / 8, "%s[%zu] = 0x%016llx is not a canonical field element", names[i], bad, (unsigned long long)((const u64 *)parts[i])[bad]);
+    }
+    u64 ck = fnv1a((const unsigned char *)&h, CHECKSUM_OFFSET);
     for (int i = 0; i < 6; i++) if (lens[i]) ck = fnv1a((const unsigned char *)parts[i], lens[i], ck);
     h.checksum = ck;
     const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -149,14 +159,15 @@ int glp_circuit_file_open(const char *path, int verify_checksum, glp_circuit_fil
     Header h;
     memcpy(&h, m, sizeof(h));
     GLP_REQUIRE(memcmp(h.magic, MAGIC, 8) == 0, "%s: not a circuit file (bad magic)", path);
-    if (h.version != VERSION) return set_error(GLP_ERR_UNSUPPORTED, "%s: circuit-file version %u, this build reads version %u", path, h.version, VERSION);
+    if (h.version != VERSION && h.version != 1) return set_error(GLP_ERR_UNSUPPORTED, "%s: circuit-file version %u, this build reads versions 1 and %u", path, h.version, VERSION);
     GLP_REQUIRE(h.header_bytes == HEADER_BYTES && h.has_witness <= 1 && h.scalars[13] <= 16 && h.hasher <= 1, "%s: malformed header", path);
     Sizes s;
     GLP_REQUIRE(sizes_of(h, s), "%s: circuit dimensions out of range", path);
     GLP_REQUIRE(s.total == f->len, "%s: %zu bytes, the header describes %zu (truncated or padded file)", path, f->len, s.total);
     const unsigned char *base = (const unsigned char *)m;
     if (verify_checksum) {
-        const u64 ck = fnv1a(base + HEADER_BYTES, f->len - HEADER_BYTES);
+        const u64 seed = h.version >= 2 ? fnv1a(base, CHECKSUM_OFFSET) : 0xcbf29ce484222325ull;      // version 2 covers the header too
+        const u64 ck = fnv1a(base + HEADER_BYTES, f->len - HEADER_BYTES, seed);
         GLP_REQUIRE(ck == h.checksum, "%s: checksum mismatch (file corrupted)", path);
     }
     glp_circuit_desc &d = f->desc;
@@ -174,6 +185,16 @@ int glp_circuit_file_open(const char *path, int verify_checksum, glp_circuit_fil
     d.constants = (const u64 *)(base + o); o += s.consts;
     d.sigmas = (const u64 *)(base + o); o += s.sigmas;
     if (h.has_witness) { f->wires = (const u64 *)(base + o); o += s.wires; f->pis = (const u64 *)(base + o); }
+    {
+        const u64 *sec[5] = {d.k_is, d.constants, d.sigmas, f->wires, f->pis};
+        const size_t cnt[5] = {s.k_is / 8, s.consts / 8, s.sigmas / 8, s.wires / 8, s.pis / 8};
+        const char *names[5] = {"k_is", "constants", "sigmas", "wires", "public_inputs"};
+        for (int i = 0; i < 5; i++) {
+            if (!cnt[i]) continue;
+            const size_t bad = glp::first_noncanonical(sec[i], cnt[i]);
+            GLP_REQUIRE(bad == cnt[i], "%s: %s[%zu] = 0x%016llx is not a canonical field element (>= p)", path, names[i], bad, (unsigned long long)sec[i][bad]);
+        }
+    }
     *out = f.release();
     return GLP_OK;
 }

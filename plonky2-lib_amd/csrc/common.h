@@ -36,6 +36,19 @@ int set_error(int code, const char *fmt, ...);
 struct NttPlan;
 struct LdePlan;
 
+// index of the first word >= p, or count if every word is a canonical field element (host; the inner loop vectorises).
+// The kernels assume canonical inputs: a word >= p gives a silently wrong proof, so the entry points that take field arrays
+// from outside (circuit description, hand-off file) reject it by name.
+inline size_t first_noncanonical(const u64 *v, size_t count) {
+    for (size_t i0 = 0; i0 < count; i0 += 4096) {
+        const size_t i1 = i0 + 4096 < count ? i0 + 4096 : count;
+        u64 bad = 0;
+        for (size_t i = i0; i < i1; i++) bad |= (u64)(v[i] >= glf::P);
+        if (bad) for (size_t i = i0; i < i1; i++) if (v[i] >= glf::P) return i;
+    }
+    return count;
+}
+
 struct Stage {
     std::string name;
     hipEvent_t beg, end;
@@ -56,6 +69,8 @@ struct glp_ctx {
     std::map<int, glp::NttPlan *> ntt_plans;                       // key: log_n
     std::map<std::pair<std::pair<int, int>, u64>, glp::LdePlan *> lde_plans;  // key: ((log_n, rate_bits), shift)
     unsigned long long lde_clock = 0;                              // LRU stamps for lde_plans
+    int two_pass_lg = 22;                // largest log_n transformed in two passes (ntt.h NTT_2PASS_LG; GLP_NTT_2PASS_LG overrides, 20..22)
+    int strided32_lw = 4;                // log2 columns of a k_strided32 tile (GLP_NTT_STRIDED32_LW: 3 = 64-byte row segments, 4 = 128-byte)
     void *host_pool = nullptr;           // HostPool of prover_batch.inc (host threads for the transcripts of a batch), made on first use
     void (*host_pool_free)(void *) = nullptr;
     bool profiling = false;

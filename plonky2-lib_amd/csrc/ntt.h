@@ -8,16 +8,20 @@
 // An inverse transform is decimation-in-frequency (natural -> bit-reversed), a forward one
 // decimation-in-time (bit-reversed -> natural), so no permutation pass ever touches HBM.
 // A size-n transform is two LDS-staged passes, n = A * B: a strided pass over A rows (tile A x 16
-// columns, 128-byte row segments) and a contiguous pass over B <= 4096 elements.
+// columns, 128-byte row segments) and a contiguous pass over B <= 4096 elements.  A <= 256 fits the
+// 32 KB tiles of k_strided16; A = 512 / 1024 (n = 2^21 / 2^22) use the 160 KB LDS of gfx950
+// (k_strided32: radix-32 x radix-16/32 register transforms, tiles of 64-128 KB).
 #pragma once
 #include "common.h"
 
 namespace glp {
 
-constexpr int NTT_2PASS_LG = 20;    // two-pass limit: B <= 2^12 (contiguous), A <= 2^8 (strided)
-constexpr int NTT_MAX_LG = 24;      // above 2^20: an outer strided pass over A' = n / 2^20 <= 16 blocks (three passes)
+constexpr int NTT_2PASS_LG = 22;    // two-pass limit: B <= 2^12 (contiguous), A <= 2^10 (strided; 2^9 and 2^10 in k_strided32).
+                                    // glp_ctx::two_pass_lg (GLP_NTT_2PASS_LG in the environment: 20..22) lowers it per context
+constexpr int NTT_INNER_LG = 20;    // above the two-pass limit: per 2^20 block the two-pass transform, then an outer strided pass
+constexpr int NTT_MAX_LG = 24;      //   over A' = n / 2^20 <= 16 blocks (three passes)
 constexpr int NTT_LGB_MAX = 12;
-constexpr int NTT_LGA_MAX = 8;
+constexpr int NTT_LGA_MAX = 8;      // rows of the generic radix-2 strided tile (static LDS); the radix-32 kernel goes to 2^10
 constexpr int NTT_STRIDED_W = 16;   // columns per strided tile (16 x 8 B = one 128-B line per row)
 
 struct NttPlan {
@@ -26,7 +30,7 @@ struct NttPlan {
     u64 *tw_A = nullptr, *itw_A = nullptr;   // w_A^j / w_A^-j, j < A/2
     u64 *tw4096 = nullptr, *itw4096 = nullptr;  // w_4096^(+-j), j < 4096: inter-step twiddles of the radix-16 kernels
     u64 w_n, w_n_inv, n_inv;
-    // lg > NTT_2PASS_LG only: n = A' * 2^20
+    // three-pass plans only (lg above the context's two-pass limit): n = A' * 2^20
     int lgAo = 0;
     const NttPlan *inner = nullptr;          // the 2^20 plan
     u64 *tw_Ao = nullptr, *itw_Ao = nullptr; // w_A'^(+-j), j < A'/2
@@ -45,7 +49,7 @@ struct LdePlan {
     u64 shift;
     u64 *pre = nullptr;      // [R][B]: (s_r^A)^bitrev_B(pl),  s_r = shift * W^r
     u64 *s_r = nullptr;      // [R]
-    // lg > NTT_2PASS_LG only
+    // three-pass plans only
     const LdePlan *inner = nullptr;          // (2^20, rate_bits, shift^A')
     u64 *t0 = nullptr, *t1 = nullptr;        // outer twiddle s_r^k1o (w_n^k1o)^q = t1[r][pbo][q >> 10] * t0[pbo][q & 1023]
     u64 last_use = 0;                        // LRU stamp (glp_ctx::lde_clock); plans other LdePlans point at are pinned

@@ -5,6 +5,7 @@
 // `PolynomialBatch::from_values / from_coeffs` on the prove() path
 // [REF src/ecdsa/gadgets/ecdsa.rs:349].  No MFMA: 64-bit modular integer butterflies.
 #include <algorithm>
+#include <utility>
 #include "ntt.h"
 
 namespace glp {
@@ -28,11 +29,11 @@ int get_ntt_plan(glp_ctx *c, int lg, NttPlan **out) {
     if (it != c->ntt_plans.end()) { *out = it->second; return GLP_OK; }
     std::unique_ptr<NttPlan> p(new NttPlan());
     p->lg = lg;
-    if (lg > NTT_2PASS_LG) {
+    if (lg > c->two_pass_lg) {
         NttPlan *in;
-        GLP_TRY(get_ntt_plan(c, NTT_2PASS_LG, &in));
+        GLP_TRY(get_ntt_plan(c, NTT_INNER_LG, &in));
         p->inner = in;
-        p->lgAo = lg - NTT_2PASS_LG;
+        p->lgAo = lg - NTT_INNER_LG;
         p->lgB = in->lgB; p->lgA = in->lgA;
         p->w_n = root_of_unity(lg); p->w_n_inv = inv(p->w_n); p->n_inv = inv((u64)1 << lg);
         const size_t Ao = (size_t)1 << p->lgAo;
@@ -109,10 +110,10 @@ int get_lde_plan(glp_ctx *c, int lg, int rate_bits, u64 shift, LdePlan **out) {
     std::unique_ptr<LdePlan> p(new LdePlan());
     p->ntt = np; p->rate_bits = rate_bits; p->shift = shift;
     const int R = 1 << rate_bits;
-    if (lg > NTT_2PASS_LG) {
+    if (np->lgAo > 0) {
         const size_t Ao = (size_t)1 << np->lgAo;
         LdePlan *in;
-        GLP_TRY(get_lde_plan(c, NTT_2PASS_LG, rate_bits, pow(shift, (u64)Ao), &in));
+        GLP_TRY(get_lde_plan(c, NTT_INNER_LG, rate_bits, pow(shift, (u64)Ao), &in));
         p->inner = in;
         in->pins++;
         struct Unpin { LdePlan *q; ~Unpin() { if (q) q->pins--; } } unpin{in};     // undone if this plan is not completed
@@ -785,6 +786,133 @@ static void launch_strided16e(glp_ctx *c, const u64 *in, u64 *out, const u64 *tw
 }
 
 // ------------------------------------------------------------------------------------------
+// Strided pass for A = 32 * 2^L2 rows, L2 in {4, 5} (traces of 2^21 / 2^22 rows): the tile of A rows x Wc columns is
+// 64-128 KB -- it fits the 160 KB LDS of gfx950 and of no earlier CDNA part, and it is what keeps these sizes at TWO
+// passes over HBM (the alternative, a third k_outer pass over 2^20-point blocks, moves the whole LDE through HBM once
+// more).  Every 64th root of unity is a power of two (w_64 = 2^39), so the 32-point and 16/32-point register transforms
+// are shifts; one general multiplication per element (the inter-step twiddle w_A^(qa kb)) as in k_strided16.
+//  DIT (forward): row pb = 32 rb + ra holds k1 = A2 ka + kb (ra = bitrev5(ka), rb = bitrev_L2(kb)); out row q1 = qa + 32 qb.
+//  DIF (inverse): row i1 = A2 ia + ib natural in; out k1 = ka + 32 kb at row A2 ra + rb.
+// Threads = A2 * Wc (step 1: one (column, rb) each, 32 elements in registers; step 2: 32 / A2 items of A2 elements).
+// LDS: 32 slabs [rb][w] of A2 * Wc words, padded by Wc words so that the step-2 reads of a 32-lane group (Wc columns of
+// 32 / Wc consecutive slabs) fall on distinct banks.  grid = (B / Wc, planes); dynamic LDS = strided32_lds_bytes().
+// ------------------------------------------------------------------------------------------
+template <bool INV, int J> struct W64 {     // w_64^(+-J) = (neg ? -1 : 1) * 2^sh
+    static constexpr int e = ((INV ? 153 : 39) * J) % 192;
+    static constexpr bool neg = e >= 96;
+    static constexpr int sh = e % 96;
+};
+template <bool INV, int J> __device__ __forceinline__ void bf64_dit(u64 &u, u64 &v) {   // (u, v) -> (u + w v, u - w v)
+    u64 t;
+    if constexpr (W64<INV, J>::sh == 0) t = v; else t = mul_pow2_c<W64<INV, J>::sh>(v);
+    const u64 a = W64<INV, J>::neg ? sub(u, t) : add(u, t);
+    const u64 b = W64<INV, J>::neg ? add(u, t) : sub(u, t);
+    u = a; v = b;
+}
+template <bool INV, int J> __device__ __forceinline__ void bf64_dif(u64 &u, u64 &v) {   // (u, v) -> (u + v, (u - v) w)
+    const u64 a = add(u, v);
+    const u64 d = W64<INV, J>::neg ? sub(v, u) : sub(u, v);
+    if constexpr (W64<INV, J>::sh == 0) v = d; else v = mul_pow2_c<W64<INV, J>::sh>(d);
+    u = a;
+}
+// stage S of a 2^L-point transform on registers: butterflies at distance 2^S with twiddles w_(2^(S+1))^j = w_64^(j (32 >> S))
+template <bool INV, int L, int S, int... Js>
+__device__ __forceinline__ void reg_stage_dit(u64 *x, std::integer_sequence<int, Js...>) {
+    constexpr int half = 1 << S, N = 1 << L;
+#pragma unroll
+    for (int b = 0; b < N; b += 2 * half) { (bf64_dit<INV, Js * (32 >> S)>(x[b + Js], x[b + Js + half]), ...); }
+}
+template <bool INV, int L, int S, int... Js>
+__device__ __forceinline__ void reg_stage_dif(u64 *x, std::integer_sequence<int, Js...>) {
+    constexpr int half = 1 << S, N = 1 << L;
+#pragma unroll
+    for (int b = 0; b < N; b += 2 * half) { (bf64_dif<INV, Js * (32 >> S)>(x[b + Js], x[b + Js + half]), ...); }
+}
+template <bool INV, int L> __device__ __forceinline__ void dft_reg_dit(u64 *x) {         // bit-reversed in -> natural out, L <= 6
+    if constexpr (L >= 1) reg_stage_dit<INV, L, 0>(x, std::make_integer_sequence<int, 1>{});
+    if constexpr (L >= 2) reg_stage_dit<INV, L, 1>(x, std::make_integer_sequence<int, 2>{});
+    if constexpr (L >= 3) reg_stage_dit<INV, L, 2>(x, std::make_integer_sequence<int, 4>{});
+    if constexpr (L >= 4) reg_stage_dit<INV, L, 3>(x, std::make_integer_sequence<int, 8>{});
+    if constexpr (L >= 5) reg_stage_dit<INV, L, 4>(x, std::make_integer_sequence<int, 16>{});
+    if constexpr (L >= 6) reg_stage_dit<INV, L, 5>(x, std::make_integer_sequence<int, 32>{});
+}
+template <bool INV, int L> __device__ __forceinline__ void dft_reg_dif(u64 *x) {         // natural in -> bit-reversed out, L <= 6
+    if constexpr (L >= 6) reg_stage_dif<INV, L, 5>(x, std::make_integer_sequence<int, 32>{});
+    if constexpr (L >= 5) reg_stage_dif<INV, L, 4>(x, std::make_integer_sequence<int, 16>{});
+    if constexpr (L >= 4) reg_stage_dif<INV, L, 3>(x, std::make_integer_sequence<int, 8>{});
+    if constexpr (L >= 3) reg_stage_dif<INV, L, 2>(x, std::make_integer_sequence<int, 4>{});
+    if constexpr (L >= 2) reg_stage_dif<INV, L, 1>(x, std::make_integer_sequence<int, 2>{});
+    if constexpr (L >= 1) reg_stage_dif<INV, L, 0>(x, std::make_integer_sequence<int, 1>{});
+}
+constexpr size_t strided32_lds_bytes(int L2, int LW) { return (size_t)32 * (((size_t)1 << L2) + 1) * ((size_t)1 << LW) * sizeof(u64); }
+
+template <bool DIF, int L2, int LW>
+__global__ __launch_bounds__(1 << (L2 + LW)) void k_strided32(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                             const u64 *__restrict__ tw4096, int lg, int lgB) {
+    constexpr int L1 = 5, A1 = 1 << L1, A2 = 1 << L2, Wc = 1 << LW, T = A2 * Wc, SLAB = (A2 + 1) * Wc, TWS = 4096 >> (L1 + L2);
+    extern __shared__ __attribute__((aligned(16))) u64 lds32[];
+    const int tid = threadIdx.x, w = tid & (Wc - 1), g = tid >> LW;
+    const size_t n = (size_t)1 << lg, B = (size_t)1 << lgB;
+    const size_t base = (size_t)blockIdx.y * n + (size_t)blockIdx.x * Wc;
+    {
+        u64 x[A1];
+        if (!DIF) {
+#pragma unroll
+            for (int ra = 0; ra < A1; ra++) x[ra] = in[base + (size_t)(A1 * g + ra) * B + w];      // g = rb
+            dft_reg_dit<false, L1>(x);                                                             // over ka -> qa
+            const int kb = (int)(__brev((unsigned)g) >> (32 - L2));
+#pragma unroll
+            for (int qa = 0; qa < A1; qa++) lds32[qa * SLAB + g * Wc + w] = qa == 0 ? x[0] : mul_c(x[qa], tw4096[TWS * qa * kb]);
+        } else {
+#pragma unroll
+            for (int ia = 0; ia < A1; ia++) x[ia] = in[base + (size_t)(A2 * ia + g) * B + w];      // g = ib
+            dft_reg_dif<true, L1>(x);                                                              // over ia -> ka at x[ra]
+#pragma unroll
+            for (int ra = 0; ra < A1; ra++) {
+                const int ka = (int)(__brev((unsigned)ra) >> (32 - L1));
+                lds32[ra * SLAB + g * Wc + w] = ka == 0 ? x[ra] : mul_c(x[ra], tw4096[TWS * g * ka]);   // itw table passed in
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < A1 / A2; j++) {
+        const int id = j * T + tid, w2 = id & (Wc - 1), a = id >> LW;                              // a = qa (DIT) / ra (DIF)
+        u64 y[A2];
+#pragma unroll
+        for (int gg = 0; gg < A2; gg++) y[gg] = lds32[a * SLAB + gg * Wc + w2];
+        if (!DIF) {
+            dft_reg_dit<false, L2>(y);                                                             // over kb -> qb
+#pragma unroll
+            for (int qb = 0; qb < A2; qb++) out[base + (size_t)(a + A1 * qb) * B + w2] = y[qb];
+        } else {
+            dft_reg_dif<true, L2>(y);                                                              // over ib -> kb at y[rb]
+#pragma unroll
+            for (int rb = 0; rb < A2; rb++) out[base + (size_t)(A2 * a + rb) * B + w2] = y[rb];
+        }
+    }
+}
+template <bool DIF, int L2, int LW>
+static int launch_strided32_t(glp_ctx *c, const u64 *in, u64 *out, const u64 *tw, int lg, int lgB, u32 planes) {
+    constexpr size_t bytes = strided32_lds_bytes(L2, LW);
+    static bool attr_set[64] = {};               // per device: tiles above 64 KB need the dynamic-LDS attribute raised once
+    if (!attr_set[c->device & 63]) {
+        GLP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided32<DIF, L2, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        attr_set[c->device & 63] = true;
+    }
+    const dim3 g((unsigned)(((size_t)1 << lgB) >> LW), planes), b(1u << (L2 + LW));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided32<DIF, L2, LW>), g, b, bytes, c->stream, in, out, tw, lg, lgB);
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
+template <bool DIF>
+static int launch_strided32(glp_ctx *c, const u64 *in, u64 *out, const u64 *tw, int lg, int lgA, int lgB, u32 planes) {
+    const bool narrow = c->strided32_lw == 3;
+    if (lgA == 9) return narrow ? launch_strided32_t<DIF, 4, 3>(c, in, out, tw, lg, lgB, planes) : launch_strided32_t<DIF, 4, 4>(c, in, out, tw, lg, lgB, planes);
+    return narrow ? launch_strided32_t<DIF, 5, 3>(c, in, out, tw, lg, lgB, planes) : launch_strided32_t<DIF, 5, 4>(c, in, out, tw, lg, lgB, planes);
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static size_t contig_lds_bytes(int lgB) { return (((size_t)1 << lgB) + ((size_t)1 << lgB) / 2 + 1 + 64 + 64 + 16) * sizeof(u64); }
@@ -795,7 +923,7 @@ static int lde_coeffs_chunk(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32
 int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift) {
     if (lg < 0 || lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d outside the supported range 0..%d", lg, NTT_MAX_LG);
     if (rate_bits < 0 || rate_bits > 4) return set_error(GLP_ERR_UNSUPPORTED, "rate_bits=%d outside 0..4", rate_bits);
-    const u32 per = 65535u >> (rate_bits + (lg > NTT_2PASS_LG ? lg - NTT_2PASS_LG : 0));
+    const u32 per = 65535u >> (rate_bits + (lg > c->two_pass_lg ? lg - NTT_INNER_LG : 0));
     const size_t n = (size_t)1 << lg;
     for (u32 c0 = 0; c0 < ncols; c0 += per)
         GLP_TRY(lde_coeffs_chunk(c, dev_coeffs + (size_t)c0 * n, dev_lde + ((size_t)c0 * n << rate_bits), std::min(per, ncols - c0), lg, rate_bits, shift));
@@ -809,11 +937,11 @@ static int lde_coeffs_chunk(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32
     const int R = 1 << rate_bits;
     if (ncols > 65535u || ((u64)ncols * R << np->lgAo) > 65535u)
         return set_error(GLP_ERR_UNSUPPORTED, "ncols*2^rate_bits*outer blocks=%llu exceeds grid.y", ((unsigned long long)ncols * R) << np->lgAo);
-    if (lg > NTT_2PASS_LG) {
+    if (np->lgAo > 0) {
         // three passes: per 2^20 block the two-pass coset transform with shift^A', the outer twiddle, then A' rows at stride 2^20
         const NttPlan *in = np->inner;
         const LdePlan *lin = lp->inner;
-        const int lgAo = np->lgAo, lgM = NTT_2PASS_LG;
+        const int lgAo = np->lgAo, lgM = NTT_INNER_LG;
         hipLaunchKernelGGL(k_lde_contig16, dim3(1u << in->lgA, ncols << lgAo), dim3(TPB), 0, c->stream, dev_coeffs, dev_lde, in->tw4096,
                            lin->pre, lin->s_r, in->w_n, lgM, in->lgA, R, lgAo);
         GLP_HIP(hipGetLastError());
@@ -841,6 +969,10 @@ static int lde_coeffs_chunk(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32
             launch_outer<false, false>(c, dev_lde, dev_lde, nullptr, nullptr, np->lgA, np->lgB, 1, ncols * R);
         else if (np->lgA >= 5 && np->lgA <= 7 && np->lgB == 12)
             launch_strided16e<false>(c, dev_lde, dev_lde, np->tw4096, lg, np->lgA, np->lgB, ncols * R);
+        else if (np->lgA >= 9 && np->lgA <= 10 && np->lgB == 12)
+            GLP_TRY(launch_strided32<false>(c, dev_lde, dev_lde, np->tw4096, lg, np->lgA, np->lgB, ncols * R));
+        else if (np->lgA > NTT_LGA_MAX)
+            return set_error(GLP_ERR_UNSUPPORTED, "internal: no strided kernel for 2^%d rows", np->lgA);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<false>), g2, dim3(TPB), 0, c->stream, dev_lde, dev_lde, np->tw_A, lg,
                                np->lgA, np->lgB);
@@ -856,7 +988,7 @@ int ntt_coeffs_to_values(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_values, u32
 static int intt_chunk(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg);
 int intt_values_to_coeffs(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 ncols, int lg) {
     if (lg < 0 || lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d outside the supported range 0..%d", lg, NTT_MAX_LG);
-    const u32 per = 65535u >> (lg > NTT_2PASS_LG ? lg - NTT_2PASS_LG : 0);
+    const u32 per = 65535u >> (lg > c->two_pass_lg ? lg - NTT_INNER_LG : 0);
     const size_t n = (size_t)1 << lg;
     for (u32 c0 = 0; c0 < ncols; c0 += per)
         GLP_TRY(intt_chunk(c, dev_values + (size_t)c0 * n, dev_coeffs + (size_t)c0 * n, std::min(per, ncols - c0), lg));
@@ -867,9 +999,9 @@ static int intt_chunk(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 nc
     NttPlan *np;
     GLP_TRY(get_ntt_plan(c, lg, &np));
     if (ncols > 65535u || ((u64)ncols << np->lgAo) > 65535u) return set_error(GLP_ERR_UNSUPPORTED, "ncols=%u exceeds grid.y", ncols);
-    if (lg > NTT_2PASS_LG) {
+    if (np->lgAo > 0) {
         const NttPlan *in = np->inner;
-        const int lgAo = np->lgAo, lgM = NTT_2PASS_LG;
+        const int lgAo = np->lgAo, lgM = NTT_INNER_LG;
         launch_outer<true, true>(c, dev_values, dev_coeffs, np->it0, np->it1, lgAo, lgM, 1, ncols);
         GLP_HIP(hipGetLastError());
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<true>), dim3((1u << in->lgB) / NTT_STRIDED_W, ncols << lgAo), dim3(TPB), 0, c->stream,
@@ -890,6 +1022,10 @@ static int intt_chunk(glp_ctx *c, const u64 *dev_values, u64 *dev_coeffs, u32 nc
             launch_outer<true, false>(c, dev_values, dev_coeffs, nullptr, nullptr, np->lgA, np->lgB, 1, ncols);
         else if (np->lgA >= 5 && np->lgA <= 7 && np->lgB == 12)
             launch_strided16e<true>(c, dev_values, dev_coeffs, np->itw4096, lg, np->lgA, np->lgB, ncols);
+        else if (np->lgA >= 9 && np->lgA <= 10 && np->lgB == 12)
+            GLP_TRY(launch_strided32<true>(c, dev_values, dev_coeffs, np->itw4096, lg, np->lgA, np->lgB, ncols));
+        else if (np->lgA > NTT_LGA_MAX)
+            return set_error(GLP_ERR_UNSUPPORTED, "internal: no strided kernel for 2^%d rows", np->lgA);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided<true>), g1, dim3(TPB), 0, c->stream, dev_values, dev_coeffs, np->itw_A,
                                lg, np->lgA, np->lgB);

@@ -1965,6 +1965,16 @@ int glp_circuit_create(glp_ctx *c, const glp_circuit_desc *desc, glp_circuit **o
         maxc = std::max(maxc, g.num_constraints);
     }
     GLP_REQUIRE(maxc <= d.num_gate_constraints, "num_gate_constraints smaller than a gate's constraint count");
+    {   // field arrays from outside: canonical or rejected by name (one host pass, small against the uploads and the commitment below)
+        const size_t nrows = (size_t)1 << d.degree_bits;
+        const u64 *sec[3] = {d.k_is, d.constants, d.sigmas};
+        const size_t cnt[3] = {d.num_routed_wires, (size_t)d.num_constants * nrows, (size_t)d.num_routed_wires * nrows};
+        const char *names[3] = {"k_is", "constants", "sigmas"};
+        for (int i = 0; i < 3; i++) {
+            const size_t bad = first_noncanonical(sec[i], cnt[i]);
+            GLP_REQUIRE(bad == cnt[i], "%s[%zu] = 0x%016llx is not a canonical field element (>= p)", names[i], bad, (unsigned long long)sec[i][bad]);
+        }
+    }
 
     std::unique_ptr<glp_circuit, void (*)(glp_circuit *)> cc(new glp_circuit(), glp_circuit_free);
     cc->ctx = c;

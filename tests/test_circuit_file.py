@@ -112,8 +112,20 @@ def test_damaged_files_are_errors(tmp_path):
     expect_error(raw + b"\0" * 8, "truncated or padded")
     bad = bytearray(raw); bad[0] = ord("X")
     expect_error(bad, "magic")
-    bad = bytearray(raw); bad[8] = 2
+    bad = bytearray(raw); bad[8] = 3
     expect_error(bad, "version")
+    assert struct.unpack_from("<I", raw, 8)[0] == 2                   # the writer's version: its checksum covers the header too
+    bad = bytearray(raw); struct.pack_into("<I", bad, 60, 27)          # num_query_rounds 28 -> 27: only the header changes
+    expect_error(bad, "checksum")
+    # a word >= p in a field section is an error even with a consistent checksum (the kernels assume canonical inputs)
+    bad = bytearray(raw)
+    off = 192 + 32 * len(desc.gates) + 8 * desc.num_routed_wires + 8 * 77          # constants[0][77]
+    struct.pack_into("<Q", bad, off, glp.P + 5)
+    h = 0xcbf29ce484222325
+    for b in bytes(bad[:184]) + bytes(bad[192:]):
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    struct.pack_into("<Q", bad, 184, h)
+    expect_error(bad, "constants[77]")
     bad = bytearray(raw); struct.pack_into("<I", bad, 16, 40)        # degree_bits = 40
     expect_error(bad, "out of range")
     expect_error(raw[:100], "shorter than")

@@ -60,7 +60,10 @@ def test_bench_gpus_flag_is_honoured_without_a_launcher():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3"], capture_output=True, text=True, env=env, timeout=300)
+    # the cheapest workload there is (2^12-row stand-in, one step, no CPU baseline, no variants): on a host that does have three
+    # GPUs this unmarked test must not run the headline bench on them for minutes
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--no-cpu-baseline", "--no-variants", "--circuit", "stand-in",
+                        "--log-n", "12", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=300)
     import torch
     if torch.cuda.device_count() < 3:
         assert r.returncode != 0 and "--gpus 3" in r.stderr and "visible" in r.stderr

@@ -143,9 +143,7 @@ def test_batch_from_coeffs_parity(ctx, oracle, ncols, lg):
     b.free()
 
 
-@pytest.mark.parametrize("lg", [21, 22])
-def test_three_pass_transforms(ctx, oracle, lg):
-    """2^21 and 2^22 points: the outer strided pass over 2^20-point blocks."""
+def _check_transforms(ctx, oracle, lg, lde_rb):
     rng = np.random.default_rng(lg)
     a = oracle.rand_field(rng, (2, 1 << lg))
     f = ctx.fft(a)
@@ -153,12 +151,40 @@ def test_three_pass_transforms(ctx, oracle, lg):
     i = ctx.ifft(a)
     assert (i[1] == oracle.ifft(a[1])).all()
     assert (ctx.ifft(f) == a).all()
-    if lg == 21:
-        got = ctx.lde(a[:1], 3, 7)
-        assert (got[0] == oracle.lde(a[0], 3, 7)).all()
+    if lde_rb:
+        got = ctx.lde(a[:1], lde_rb, 7)
+        assert (got[0] == oracle.lde(a[0], lde_rb, 7)).all()
 
 
-def test_three_pass_batch(ctx, oracle):
+@pytest.mark.parametrize("lg,lde_rb", [(21, 3), (22, 1), (23, 0)])
+def test_large_transforms(ctx, oracle, lg, lde_rb):
+    """2^21 and 2^22 points: still TWO passes, the strided one on 512- / 1024-row tiles in the 160 KB LDS (k_strided32);
+    2^23: three passes (k_outer over 2^20-point blocks)."""
+    _check_transforms(ctx, oracle, lg, lde_rb)
+
+
+@pytest.mark.parametrize("env", [{"GLP_NTT_2PASS_LG": "20"}, {"GLP_NTT_STRIDED32_LW": "3"}])
+def test_large_transform_switches(oracle, env):
+    """The tuning switches a context reads at creation (include/glp.h): the three-pass path at 2^21 (what round 2 shipped, kept
+    for the A/B rows in profiles/) and the 8-column (64-byte row segment) form of the k_strided32 tile."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c2 = glp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    try:
+        _check_transforms(c2, oracle, 21, 1)
+    finally:
+        c2.close()
+
+
+def test_large_batch_2_21(ctx, oracle):
     rng = np.random.default_rng(77)
     vals = oracle.rand_field(rng, (5, 1 << 21))
     ref = oracle.batch_from_values(vals, 3, 4)

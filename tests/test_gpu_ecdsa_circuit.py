@@ -68,6 +68,79 @@ def test_two_signatures_batch_circuit(ctx, oracle):
     gc.free()
 
 
+def _gate_row(c, gtype, which=0, nth=100):
+    """(gate index, a trace row) of the `which`-th gate of type `gtype`: rows carry their gate's index in the selector column"""
+    import plonky2_lib_amd.synth as synth  # noqa: F401
+    gi = [i for i, g in enumerate(c.gates) if g["type"] == gtype][which]
+    rows = np.nonzero(c.constants[c.gates[gi]["selector_index"]] == np.uint64(gi))[0]
+    return gi, int(rows[min(nth, len(rows) - 1)])
+
+
+def _bump(w, col, row):
+    w[col, row] = np.uint64((int(w[col, row]) + 1) % glp.P)
+
+
+def test_headline_ten_signatures_2_20(ctx, oracle):
+    """THE workload `bench.py` times by default: `gadgets_ecdsa.ecdsa_circuit(random_signatures(10, ...), min_log_n=20)` -- ten
+    secp256k1 signatures in one 2^20-row x 136-wire trace, 17 gates in 4 selector groups (ten base-4 limb gates: the two
+    k_quotient_limbs groups), `test_batch_ecdsa_circuit_with_config` [REF src/ecdsa/gadgets/ecdsa.rs:214-353; driver
+    REF src/bin/perf.rs:7-9]: prove, then verify.  Both verifiers (the library's and the oracle's) must accept; six tampered words,
+    a U32AddMany limb off by one and a ComparisonGate chunk off by one must be rejected; `glp_prove_device` (what the bench
+    calls) and `glp_prove` (host witness) must return the same words."""
+    import plonky2_lib_amd.synth as synth
+    SEED = 0x5EED0003                                          # bench.py's seed for rank 0
+    c = E.ecdsa_circuit(E.random_signatures(10, seed=SEED), min_log_n=20)
+    assert c.degree_bits == 20 and c.num_wires == 136 and len(c.gates) == 17
+    assert sum(1 for g in c.gates if g["type"] in (synth.GATE_U32_ARITHMETIC, synth.GATE_U32_ADD_MANY, synth.GATE_U32_SUBTRACTION,
+                                                    synth.GATE_U32_RANGE_CHECK)) == 10
+    gc = glp.Circuit(ctx, c)
+    proof = gc.prove()                                         # glp_prove: witness from host memory
+    c.circuit_digest = gc.digest()
+    oc = oracle.OracleCircuit(c, cs_cap=gc.constants_sigmas_cap())
+    assert gc.verify(proof) and oc.verify(proof) == 0
+    w = np.ascontiguousarray(c.wires)
+    dptr = ctx.dev_alloc(w.nbytes)
+    ctx.dev_upload(dptr, w)
+    assert (gc.prove_device(dptr) == proof).all()              # the entry point the bench times
+    rng = np.random.default_rng(20)
+    for pos in [int(x) for x in rng.integers(0, len(proof), 4)] + [0, len(proof) - 1]:
+        bad = proof.copy(); bad[pos] = np.uint64((int(bad[pos]) + 1) % glp.P)
+        assert not gc.verify(bad) and oc.verify(bad) != 0, pos
+    # one base-4 limb of a U32AddMany sum (limb columns start at (num_addends + 3) * num_ops) and one chunk of a ComparisonGate
+    # (first-input chunks start at wire 4): the witness no longer satisfies the gate, no verifier may accept the proof
+    for gtype, col_of in ((synth.GATE_U32_ADD_MANY, lambda g: (g["p0"] + 3) * g["p1"]), (synth.GATE_COMPARISON, lambda g: 4)):
+        gi, row = _gate_row(c, gtype, which=-1)
+        _bump(w, col_of(c.gates[gi]), row)
+        ctx.dev_upload(dptr, w)
+        badp = gc.prove_device(dptr)
+        assert not gc.verify(badp) and oc.verify(badp) != 0, (gtype, gi, row)
+        w[:, row] = c.wires[:, row]
+    ctx.dev_free(dptr)
+    gc.free()
+
+
+def test_perf_rs_twenty_signatures_2_21(ctx, oracle):
+    """The literal `perf` workload: `test_batch_ecdsa_circuit_with_config(20, standard_ecc_config)` [REF src/bin/perf.rs:7-9]
+    proves TWENTY signatures in one circuit.  At this repository's gate density (98 687 rows per signature; row count vs
+    plonky2's builder: parity unpinned) that is a 2^21-row trace -- past the 2^20 tile of the contiguous pass, so the strided pass
+    runs on 512-row LDS tiles.  Prove, then verify with both verifiers; a tampered word and a broken limb must be rejected."""
+    import plonky2_lib_amd.synth as synth
+    c = E.ecdsa_circuit(E.random_signatures(20, seed=0x5EED0003))
+    assert c.degree_bits == 21 and len(c.gates) == 17
+    gc = glp.Circuit(ctx, c)
+    proof = gc.prove()
+    c.circuit_digest = gc.digest()
+    oc = oracle.OracleCircuit(c, cs_cap=gc.constants_sigmas_cap())
+    assert gc.verify(proof) and oc.verify(proof) == 0
+    bad = proof.copy(); bad[len(bad) // 2] ^= np.uint64(1)
+    assert not gc.verify(bad) and oc.verify(bad) != 0
+    w = c.wires.copy()
+    gi, row = _gate_row(c, synth.GATE_U32_ARITHMETIC, nth=(1 << 20) // 8)
+    _bump(w, 6 * c.gates[gi]["p0"], row)                      # first base-4 limb of op 0's low output word
+    assert not gc.verify(gc.prove(wires=w))
+    gc.free()
+
+
 @pytest.mark.parametrize("which", ["fixed_base", "glv", "msm", "bitwise", "windowed"])
 def test_scalar_multiplication_gadgets(ctx, oracle, which):
     """The three scalar-multiplication circuits the verification is made of, each as the reference tests it on its own:

@@ -53,6 +53,7 @@ GLP_API int glp_device_count(void);
 /* Environment variables read when a context is made (tuning switches for the A/B rows under profiles/; the defaults ship):
  *   GLP_NTT_2PASS_LG      = 20..22 (default 22): largest log2(n) transformed in two passes; above it a third pass over 2^20-point blocks
  *   GLP_NTT_STRIDED32_LW  = 3 | 4  (default 4):  log2 columns of the 512- / 1024-row strided tile (64- or 128-byte row segments)
+ *   GLP_NTT_STRIDED32_TL  = 1..64  (default 8):  tiles one block of that kernel walks, software-pipelined (1 = one tile per block)
  *   GLP_HOST_THREADS      (read on the first glp_prove_batch of a context): host threads for the transcripts of a batch */
 GLP_API int glp_ctx_create(int device_id, glp_ctx **out);
 GLP_API void glp_ctx_destroy(glp_ctx *ctx);
@@ -241,6 +242,29 @@ GLP_API int glp_prove(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *
                       uint64_t *proof_out);
 GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *dev_wires,
                              const uint64_t *public_inputs, uint64_t *proof_out);
+
+/* ---- witnesses that start in host memory, pipelined -------------------------------------------------------------------
+ * `data.prove(pw)` starts from a witness the CPU has just generated [REF src/ecdsa/gadgets/ecdsa.rs:332-349: set the targets, then
+ * prove].  glp_prove(host wires) uploads it inside the call; a caller that proves witness after witness hides the upload behind
+ * the previous proof instead:
+ *     glp_witness_stage(ctx, circuit, wires[i+1], flags, &w_next);        returns at once: the copy runs on the ctx's copy stream
+ *     glp_prove_staged(ctx, circuit, w_cur, public_inputs, proof_out);    the compute stream waits for w_cur's copy, then proves
+ *     glp_witness_free(w_cur);
+ * For the copy to overlap anything the host buffer must be page-locked: glp_host_alloc hands out such memory (have witness
+ * generation write into it); pageable memory works and is staged by the HIP runtime, synchronously.
+ * GLP_WITNESS_ROUTED_ONLY: host_wires holds only the routed columns [num_routed_wires][n] (= the first columns of the full
+ * [num_wires][n] layout, so the full array may be passed as well); the advice columns are zero-filled on the device and derived
+ * there by glp_witness_fill(only_advice) before the proof starts -- for the secp256k1 trace 56 of 136 columns (41 %) never cross
+ * PCIe.  The proof is word for word the proof of the complete witness provided every advice wire of the witness is either
+ * written by a row-local generator or zero (true for witnesses of plonky2's generators; tests/test_gpu_witness.py). */
+typedef struct glp_witness glp_witness;
+#define GLP_WITNESS_ROUTED_ONLY 1u
+GLP_API int glp_host_alloc(glp_ctx *ctx, size_t bytes, void **host_out);      /* page-locked host memory */
+GLP_API int glp_host_free(glp_ctx *ctx, void *host);
+GLP_API int glp_witness_stage(glp_ctx *ctx, const glp_circuit *circuit, const uint64_t *host_wires, uint32_t flags, glp_witness **out);
+GLP_API int glp_prove_staged(glp_ctx *ctx, const glp_circuit *circuit, glp_witness *witness, const uint64_t *public_inputs,
+                             uint64_t *proof_out);
+GLP_API void glp_witness_free(glp_witness *witness);
 
 /* Many independent proofs of ONE circuit in lock step (BASELINE config 5: a batch of zkdsa simple-signature proofs, the unit
  * [REF src/zkdsa/circuits/mod.rs:24-43,322-339] proves one at a time).  Small circuits are bound by launch and host round-trip

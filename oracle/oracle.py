@@ -378,6 +378,18 @@ class OracleCircuit:
         with _Hasher(self.hasher):
             return lib().glo_verify(C.byref(self.s), _p(self.cs_cap), _p(_a(proof)))
 
+    def proof_to_bytes(self, proof):
+        """gl_proof_bytes.c: `ProofWithPublicInputs::to_bytes()` restated along the Rust writer's call tree (recalled, unpinned)."""
+        L = lib()
+        L.glo_proof_to_bytes.restype = C.c_size_t
+        w = _a(proof)
+        assert w.size == self.proof_words
+        with _Hasher(self.hasher):
+            n = L.glo_proof_to_bytes(C.byref(self.s), _p(w), None, C.c_size_t(0))
+            out = np.empty(n, np.uint8)
+            assert L.glo_proof_to_bytes(C.byref(self.s), _p(w), out.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == n
+        return out.tobytes()
+
 
 def circuit_digest(constants_sigmas_cap, degree_bits, hasher=0):
     """plonk/circuit_builder.rs build(): C::Hasher::hash_no_pad(cap.flatten() ++ hash_pad(domain_separator = []).to_vec() ++ [degree_bits]).

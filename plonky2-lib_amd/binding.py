@@ -133,6 +133,11 @@ def load_library():
         "glp_prove_batch": [vp, vp, u32, vp, C.c_int, vp, vp],
         "glp_witness_fill": [vp, vp, vp, C.c_int],
         "glp_witness_columns": [vp, u32, vp],
+        "glp_host_alloc": [vp, sz, C.POINTER(vp)],
+        "glp_host_free": [vp, vp],
+        "glp_witness_stage": [vp, vp, vp, u32, C.POINTER(vp)],
+        "glp_prove_staged": [vp, vp, vp, vp, vp],
+        "glp_witness_free": [vp],
         "glp_dev_alloc": [vp, sz, C.POINTER(vp)],
         "glp_dev_free": [vp, vp],
         "glp_dev_upload": [vp, vp, vp, sz],
@@ -158,6 +163,7 @@ def load_library():
     L.glp_circuit_free.restype = None
     L.glp_session_end.restype = None
     L.glp_circuit_file_close.restype = None
+    L.glp_witness_free.restype = None
     _lib = L
     return L
 
@@ -272,6 +278,21 @@ class Context:
 
     def dev_download(self, ptr, array):
         _chk(load_library().glp_dev_download(self._h, array.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), array.nbytes))
+
+    def host_alloc(self, shape):
+        """Page-locked host memory (glp_host_alloc) as a uint64 numpy array of `shape`: what witness generation should write into
+        so that glp_witness_stage's copy overlaps the proof in flight.  Free with host_free(array)."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        _chk(load_library().glp_host_alloc(self._h, max(n, 1) * 8, C.byref(p)))
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(max(n, 1),))[:n].reshape(shape)
+        self.__dict__.setdefault("_pinned", {})[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr):
+        p = self.__dict__.get("_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None and getattr(self, "_h", None):
+            _chk(load_library().glp_host_free(self._h, C.c_void_p(p)))
 
     def fill_random_device(self, dev_ptr, count, seed):
         _chk(load_library().glp_fill_random_device(self._h, C.c_void_p(dev_ptr), count, seed))
@@ -601,6 +622,25 @@ class Circuit:
         _chk(load_library().glp_witness_columns(self._h, int(gate_index), out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def stage_witness(self, host_wires, routed_only=False):
+        """glp_witness_stage: start uploading a witness on the context's copy stream ([num_wires][n], or with routed_only the routed
+        columns [num_routed_wires][n] -- the advice columns are then derived on the GPU); returns a StagedWitness for prove_staged."""
+        w = host_wires if (isinstance(host_wires, np.ndarray) and host_wires.dtype == np.uint64 and host_wires.flags.c_contiguous) else _a(host_wires)
+        n = 1 << int(self.desc.degree_bits)
+        need = (int(self.desc.num_routed_wires) if routed_only else int(self.desc.num_wires)) * n
+        if w.size < need or (not routed_only and w.size != need):
+            raise GlpError(-1, "staged witness has %d elements, expected %d" % (w.size, need))
+        h = C.c_void_p()
+        _chk(load_library().glp_witness_stage(self.ctx._h, self._h, _p(w), 1 if routed_only else 0, C.byref(h)))
+        return StagedWitness(self, h, w)
+
+    def prove_staged(self, staged, public_inputs=None):
+        pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)
+        self._check_witness(None, pi)
+        proof = np.zeros(self.proof_words, np.uint64)
+        _chk(load_library().glp_prove_staged(self.ctx._h, self._h, staged._h, _p(pi) if pi.size else None, _p(proof)))
+        return proof
+
     def prove_device(self, dev_wires_ptr, public_inputs=None):
         pi = _a(self.desc.public_inputs if public_inputs is None else public_inputs)
         self._check_witness(None, pi)
@@ -608,6 +648,26 @@ class Circuit:
         _chk(load_library().glp_prove_device(self.ctx._h, self._h, C.c_void_p(dev_wires_ptr), _p(pi) if pi.size else None,
                                              _p(proof)))
         return proof
+
+
+class StagedWitness:
+    """A witness on its way to (or in) HBM (glp_witness): keeps the host array alive until the upload has been consumed."""
+
+    def __init__(self, circuit, handle, host_array):
+        self.circuit, self._h, self._host = circuit, handle, host_array
+
+    def free(self):
+        if getattr(self, "_h", None):
+            if getattr(self.circuit.ctx, "_h", None):
+                load_library().glp_witness_free(self._h)
+            self._h = None
+            self._host = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Session:

@@ -103,6 +103,7 @@ int glp_ctx_create(int device_id, glp_ctx **out) {
     c->num_cus = prop.multiProcessorCount;
     // tuning switches (profiles/ A-B runs; documented in include/glp.h): the defaults are what ships
     if (const char *e1 = getenv("GLP_NTT_2PASS_LG")) { const int v = atoi(e1); if (v >= NTT_INNER_LG && v <= NTT_2PASS_LG) c->two_pass_lg = v; }
+    if (const char *e2 = getenv("GLP_NTT_STRIDED32_TL")) { const int v = atoi(e2); if (v >= 1 && v <= 64) c->strided32_tl = v; }
     if (const char *e3 = getenv("GLP_NTT_STRIDED32_LW")) { const int v = atoi(e3); if (v == 3 || v == 4) c->strided32_lw = v; }
     GLP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {

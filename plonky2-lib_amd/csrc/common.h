@@ -70,6 +70,7 @@ struct glp_ctx {
     std::map<std::pair<std::pair<int, int>, u64>, glp::LdePlan *> lde_plans;  // key: ((log_n, rate_bits), shift)
     unsigned long long lde_clock = 0;                              // LRU stamps for lde_plans
     int two_pass_lg = 22;                // largest log_n transformed in two passes (ntt.h NTT_2PASS_LG; GLP_NTT_2PASS_LG overrides, 20..22)
+    int strided32_tl = 8;                // tiles (planes) a k_strided32 block walks, software-pipelined (GLP_NTT_STRIDED32_TL: 1..64; 1 = no pipelining)
     int strided32_lw = 4;                // log2 columns of a k_strided32 tile (GLP_NTT_STRIDED32_LW: 3 = 64-byte row segments, 4 = 128-byte)
     void *host_pool = nullptr;           // HostPool of prover_batch.inc (host threads for the transcripts of a batch), made on first use
     void (*host_pool_free)(void *) = nullptr;

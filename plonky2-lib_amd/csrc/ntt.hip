@@ -844,52 +844,92 @@ template <bool INV, int L> __device__ __forceinline__ void dft_reg_dif(u64 *x) {
     if constexpr (L >= 2) reg_stage_dif<INV, L, 1>(x, std::make_integer_sequence<int, 2>{});
     if constexpr (L >= 1) reg_stage_dif<INV, L, 0>(x, std::make_integer_sequence<int, 1>{});
 }
-constexpr size_t strided32_lds_bytes(int L2, int LW) { return (size_t)32 * (((size_t)1 << L2) + 1) * ((size_t)1 << LW) * sizeof(u64); }
+constexpr size_t strided32_lds_bytes(int L2, int LW) { return ((size_t)32 * (((size_t)1 << L2) + 1) * ((size_t)1 << LW) + ((size_t)32 << L2)) * sizeof(u64); }
 
+// One tile = three phases (load, two register transforms around the LDS exchange, store).  With 64-128 KB of LDS per block
+// only one or two blocks fit a CU, so the phases of DIFFERENT blocks cannot cover each other as they do for the 32 KB tiles of
+// k_strided16 (measured: load + compute + store in sequence, 29 ms for the 2^22 wires LDE against 17 ms of HBM time).  The
+// kernel therefore walks TL tiles (same columns, consecutive planes) per block and software-pipelines them: the loads of tile
+// t + 1 are issued right after tile t's step-1 values have gone to LDS and stay in flight across the exchange, the second
+// transform and the stores of tile t (~130 VGPRs at 2 waves per SIMD).
+// Addresses are "uniform base (SGPR pair) + 32-bit per-thread byte offset": the row part of every load / store is the same for
+// all threads, so it stays in scalar registers (global_load ... v_off, s[base]) instead of 32 + 32 per-thread 64-bit addresses
+// that the compiler would otherwise keep live across the tile loop (the first form of this kernel needed > 256 VGPRs and spilled).
+__device__ __forceinline__ u64 ld_su(const u64 *ubase, u32 byte_off) { return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(ubase) + byte_off); }
+__device__ __forceinline__ void st_su(u64 *ubase, u32 byte_off, u64 v) { *reinterpret_cast<u64 *>(reinterpret_cast<char *>(ubase) + byte_off) = v; }
 template <bool DIF, int L2, int LW>
-__global__ __launch_bounds__(1 << (L2 + LW)) void k_strided32(const u64 *__restrict__ in, u64 *__restrict__ out,
-                                                             const u64 *__restrict__ tw4096, int lg, int lgB) {
-    constexpr int L1 = 5, A1 = 1 << L1, A2 = 1 << L2, Wc = 1 << LW, T = A2 * Wc, SLAB = (A2 + 1) * Wc, TWS = 4096 >> (L1 + L2);
-    extern __shared__ __attribute__((aligned(16))) u64 lds32[];
-    const int tid = threadIdx.x, w = tid & (Wc - 1), g = tid >> LW;
-    const size_t n = (size_t)1 << lg, B = (size_t)1 << lgB;
-    const size_t base = (size_t)blockIdx.y * n + (size_t)blockIdx.x * Wc;
-    {
-        u64 x[A1];
-        if (!DIF) {
+__device__ __forceinline__ void s32_load(u64 *x, const u64 *__restrict__ tile /* uniform: first element of the tile */, size_t B, int g, int w) {
+    constexpr int A1 = 32, A2 = 1 << L2;
+    const u32 toff = (u32)(((size_t)(DIF ? g : A1 * g) * B + (size_t)w) * 8);                      // DIT: g = rb, r = ra; DIF: g = ib, r = ia
 #pragma unroll
-            for (int ra = 0; ra < A1; ra++) x[ra] = in[base + (size_t)(A1 * g + ra) * B + w];      // g = rb
-            dft_reg_dit<false, L1>(x);                                                             // over ka -> qa
-            const int kb = (int)(__brev((unsigned)g) >> (32 - L2));
+    for (int r = 0; r < A1; r++) x[r] = ld_su(tile + (size_t)(DIF ? A2 * r : r) * B, toff);
+}
+// step 1: 32-point transform on registers, inter-step twiddle, to LDS.  The twiddles w_A^(qa kb) come from a per-block LDS copy
+// twl[g][32] (4-8 KB behind the tile), NOT from global memory: a global load issued here would sit behind the stores of the
+// previous tile in the in-order vmcnt queue, and waiting for it would wait for those stores -- the pipelining would be gone.
+template <bool DIF, int L2, int LW>
+__device__ __forceinline__ void s32_step1(u64 *x, u64 *lds32, const u64 *twl, int g, int w) {
+    constexpr int L1 = 5, A1 = 32, A2 = 1 << L2, Wc = 1 << LW, SLAB = (A2 + 1) * Wc;
+    if (!DIF) dft_reg_dit<false, L1>(x);           // over ka -> qa
+    else dft_reg_dif<true, L1>(x);                 // over ia -> ka at x[ra]
+    const u64 *tw = twl + A1 * g;
 #pragma unroll
-            for (int qa = 0; qa < A1; qa++) lds32[qa * SLAB + g * Wc + w] = qa == 0 ? x[0] : mul_c(x[qa], tw4096[TWS * qa * kb]);
-        } else {
-#pragma unroll
-            for (int ia = 0; ia < A1; ia++) x[ia] = in[base + (size_t)(A2 * ia + g) * B + w];      // g = ib
-            dft_reg_dif<true, L1>(x);                                                              // over ia -> ka at x[ra]
-#pragma unroll
-            for (int ra = 0; ra < A1; ra++) {
-                const int ka = (int)(__brev((unsigned)ra) >> (32 - L1));
-                lds32[ra * SLAB + g * Wc + w] = ka == 0 ? x[ra] : mul_c(x[ra], tw4096[TWS * g * ka]);   // itw table passed in
-            }
-        }
-    }
-    __syncthreads();
+    for (int q = 0; q < A1; q++) lds32[q * SLAB + g * Wc + w] = q == 0 ? x[0] : mul_c(x[q], tw[q]);      // q = qa (DIT) / ra (DIF); tw[0] = 1
+}
+template <bool DIF, int L2, int LW>
+__device__ __forceinline__ void s32_step2(const u64 *lds32, u64 *__restrict__ tile, size_t B, int tid) {
+    constexpr int A1 = 32, A2 = 1 << L2, Wc = 1 << LW, T = A2 * Wc, SLAB = (A2 + 1) * Wc;
 #pragma unroll
     for (int j = 0; j < A1 / A2; j++) {
         const int id = j * T + tid, w2 = id & (Wc - 1), a = id >> LW;                              // a = qa (DIT) / ra (DIF)
         u64 y[A2];
 #pragma unroll
         for (int gg = 0; gg < A2; gg++) y[gg] = lds32[a * SLAB + gg * Wc + w2];
+        const u32 toff = (u32)(((size_t)(DIF ? A2 * a : a) * B + (size_t)w2) * 8);
         if (!DIF) {
-            dft_reg_dit<false, L2>(y);                                                             // over kb -> qb
+            dft_reg_dit<false, L2>(y);                                                             // over kb -> qb; row a + 32 qb
 #pragma unroll
-            for (int qb = 0; qb < A2; qb++) out[base + (size_t)(a + A1 * qb) * B + w2] = y[qb];
+            for (int qb = 0; qb < A2; qb++) st_su(tile + (size_t)(A1 * qb) * B, toff, y[qb]);
         } else {
-            dft_reg_dif<true, L2>(y);                                                              // over ib -> kb at y[rb]
+            dft_reg_dif<true, L2>(y);                                                              // over ib -> kb at y[rb]; row A2 a + rb
 #pragma unroll
-            for (int rb = 0; rb < A2; rb++) out[base + (size_t)(A2 * a + rb) * B + w2] = y[rb];
+            for (int rb = 0; rb < A2; rb++) st_su(tile + (size_t)rb * B, toff, y[rb]);
         }
+    }
+}
+// grid = (B / Wc, ceil(planes / TL)); block (bx, by) transforms tiles (columns bx, planes by * TL .. min(planes, by * TL + TL) - 1)
+template <bool DIF, int L2, int LW>
+__global__ __launch_bounds__(1 << (L2 + LW)) void k_strided32(const u64 *__restrict__ in, u64 *__restrict__ out,
+                                                             const u64 *__restrict__ tw4096, int lg, int lgB, u32 planes, u32 TL) {
+    constexpr int Wc = 1 << LW;
+    constexpr int L1 = 5, A1 = 32, A2 = 1 << L2, T = A2 * Wc, SLAB = (A2 + 1) * Wc, TWS = 4096 >> (L1 + L2);
+    extern __shared__ __attribute__((aligned(16))) u64 lds32[];
+    u64 *twl = lds32 + A1 * SLAB;                                   // [A2][32] inter-step twiddles
+    const int tid = threadIdx.x, w = tid & (Wc - 1), g = tid >> LW;
+    const size_t n = (size_t)1 << lg, B = (size_t)1 << lgB;
+    for (int e = tid; e < A2 * A1; e += T) {                        // DIT: w_A^(qa kb), kb = bitrev_L2(g); DIF: w_A^-(ib ka), ka = bitrev5(ra) (itw table passed in)
+        const int gg = e >> L1, q = e & (A1 - 1);
+        const int k = DIF ? gg * (int)(__brev((unsigned)q) >> (32 - L1)) : q * (int)(__brev((unsigned)gg) >> (32 - L2));
+        twl[e] = tw4096[TWS * k];
+    }
+    const u32 p0 = blockIdx.y * TL, cnt = min(TL, planes - p0);
+    const size_t base0 = (size_t)p0 * n + (size_t)blockIdx.x * Wc;      // uniform
+    in += base0; out += base0;
+    // Rotated loop: step 1 of tile i + 1 sits at the END of iteration i, behind "loads(i + 1), stores(i)" issued in that order in
+    // the same iteration, so the compiler's wait for the loads is vmcnt(32 + ..): the 32 younger stores stay in flight.  (With
+    // step 1 at the top of the loop the wait is merged with the prologue's state -- no stores yet -- and drains the stores of the
+    // previous tile every iteration.)  One copy of each step in the loop body: two would not fit the instruction cache.
+    u64 x[32];
+    s32_load<DIF, L2, LW>(x, in, B, g, w);
+    __syncthreads();                                                // twl
+    s32_step1<DIF, L2, LW>(x, lds32, twl, g, w);
+    for (u32 i = 0; i < cnt; i++) {
+        const bool more = i + 1 < cnt;
+        if (more) s32_load<DIF, L2, LW>(x, in + (size_t)(i + 1) * n, B, g, w);                     // in flight across the exchange and the stores of tile i
+        __syncthreads();
+        s32_step2<DIF, L2, LW>(lds32, out + (size_t)i * n, B, tid);
+        __syncthreads();
+        if (more) s32_step1<DIF, L2, LW>(x, lds32, twl, g, w);
     }
 }
 template <bool DIF, int L2, int LW>
@@ -900,8 +940,9 @@ static int launch_strided32_t(glp_ctx *c, const u64 *in, u64 *out, const u64 *tw
         GLP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_strided32<DIF, L2, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         attr_set[c->device & 63] = true;
     }
-    const dim3 g((unsigned)(((size_t)1 << lgB) >> LW), planes), b(1u << (L2 + LW));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided32<DIF, L2, LW>), g, b, bytes, c->stream, in, out, tw, lg, lgB);
+    const u32 TL = (u32)std::max(1, std::min<int>(c->strided32_tl, (int)planes));
+    const dim3 g((unsigned)(((size_t)1 << lgB) >> LW), (planes + TL - 1) / TL), b(1u << (L2 + LW));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided32<DIF, L2, LW>), g, b, bytes, c->stream, in, out, tw, lg, lgB, planes, TL);
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }

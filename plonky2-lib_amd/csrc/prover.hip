@@ -2239,6 +2239,70 @@ int glp_prove(glp_ctx *c, const glp_circuit *cc, const uint64_t *wires, const ui
     return rc;
 }
 
+// ---- staged witnesses (include/glp.h "witnesses that start in host memory, pipelined")
+}  // extern "C"
+struct glp_witness {
+    glp_ctx *c = nullptr;
+    const glp_circuit *cc = nullptr;
+    u64 *dev = nullptr;            // [num_wires][n], from the context's pool
+    hipEvent_t ready = nullptr;    // recorded on the copy stream behind the upload
+    bool routed_only = false, filled = false;
+};
+extern "C" {
+int glp_host_alloc(glp_ctx *c, size_t bytes, void **host_out) {
+    GLP_REQUIRE(c && host_out && bytes > 0, "null argument or zero size");
+    *host_out = nullptr;
+    GLP_TRY(bind(c));
+    GLP_HIP(hipHostMalloc(host_out, bytes, hipHostMallocDefault));
+    return GLP_OK;
+}
+int glp_host_free(glp_ctx *c, void *host) {
+    GLP_REQUIRE(c, "null context");
+    if (!host) return GLP_OK;
+    GLP_TRY(bind(c));
+    GLP_HIP(hipHostFree(host));
+    return GLP_OK;
+}
+void glp_witness_free(glp_witness *w) {
+    if (!w) return;
+    (void)hipSetDevice(w->c->device);
+    if (w->ready) { (void)hipEventSynchronize(w->ready); (void)hipEventDestroy(w->ready); }
+    if (w->dev) { (void)hipStreamSynchronize(w->c->stream); w->c->release(w->dev); }
+    delete w;
+}
+int glp_witness_stage(glp_ctx *c, const glp_circuit *cc, const uint64_t *host_wires, uint32_t flags, glp_witness **out) {
+    GLP_REQUIRE(c && cc && host_wires && out, "null argument");
+    *out = nullptr;
+    GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");
+    GLP_REQUIRE((flags & ~GLP_WITNESS_ROUTED_ONLY) == 0, "unknown flags 0x%x", flags);
+    GLP_TRY(bind(c));
+    const size_t n = (size_t)1 << cc->d.degree_bits;
+    const u32 nw = cc->d.num_wires, nr = cc->d.num_routed_wires;
+    std::unique_ptr<glp_witness, void (*)(glp_witness *)> w(new glp_witness(), glp_witness_free);
+    w->c = c; w->cc = cc; w->routed_only = (flags & GLP_WITNESS_ROUTED_ONLY) != 0;
+    void *dv = nullptr;
+    GLP_TRY(c->alloc(&dv, (size_t)nw * n * 8));
+    w->dev = (u64 *)dv;
+    GLP_HIP(hipEventCreateWithFlags(&w->ready, hipEventDisableTiming));
+    const u32 ncopy = w->routed_only ? nr : nw;
+    GLP_HIP(hipMemcpyAsync(w->dev, host_wires, (size_t)ncopy * n * 8, hipMemcpyHostToDevice, c->copy_stream));
+    if (ncopy < nw) GLP_HIP(hipMemsetAsync(w->dev + (size_t)ncopy * n, 0, (size_t)(nw - ncopy) * n * 8, c->copy_stream));
+    GLP_HIP(hipEventRecord(w->ready, c->copy_stream));
+    *out = w.release();
+    return GLP_OK;
+}
+int glp_prove_staged(glp_ctx *c, const glp_circuit *cc, glp_witness *w, const uint64_t *public_inputs, uint64_t *proof_out) {
+    GLP_REQUIRE(c && cc && w && proof_out, "null argument");
+    GLP_REQUIRE(cc->ctx == c && w->c == c && w->cc == cc, "witness, circuit and context do not belong together");
+    GLP_REQUIRE(public_inputs || cc->d.num_public_inputs == 0, "public_inputs is null");
+    GLP_TRY(bind(c));
+    GLP_HIP(hipStreamWaitEvent(c->stream, w->ready, 0));
+    if (w->routed_only && !w->filled) {
+        GLP_TRY(glp_witness_fill(c, cc, w->dev, 1));
+        w->filled = true;
+    }
+    return prove_impl(c, cc, w->dev, public_inputs, proof_out);
+}
 }  // extern "C"
 
 #include <stdlib.h>

@@ -30,8 +30,11 @@ def main():
                         constants_sigmas_cap=oc.cs_cap, public_inputs=np.asarray(desc.public_inputs, np.uint64))
     # the same circuit + witness as a circuit hand-off file (include/glp.h, glp_circuit_file_*): what a machine with the Rust
     # builder would ship to the GPU box.  Written by the PRODUCT library's writer (host code, no GPU needed).
+    # zkdsa_2_3.glpc is a VERSION 1 file (checksum over the sections only), written by the round-2 library and kept as the
+    # fixture of the reader's compatibility path: it is not regenerated.  zkdsa_2_3_v2.glpc is the same content in the current
+    # version (checksum over header and sections).
     import plonky2_lib_amd as glp
-    glp.write_circuit_file(os.path.join(HERE, "zkdsa_2_3.glpc"), desc, with_witness=True)
+    glp.write_circuit_file(os.path.join(HERE, "zkdsa_2_3_v2.glpc"), desc, with_witness=True)
 
 
 if __name__ == "__main__":

@@ -94,6 +94,20 @@ def test_committed_sample_file():
         assert (cf.desc.public_inputs == g["public_inputs"]).all()
 
 
+def test_committed_sample_file_current_version():
+    """tests/golden/zkdsa_2_3_v2.glpc: the same circuit and witness in the version the library writes now -- the checksum covers the
+    184 header bytes in front of it as well as the sections (a header field changed in transit is then an error too)."""
+    raw = open(os.path.join(GOLDEN, "zkdsa_2_3_v2.glpc"), "rb").read()
+    old = open(os.path.join(GOLDEN, "zkdsa_2_3.glpc"), "rb").read()
+    assert struct.unpack_from("<II", raw, 8) == (2, 192) and raw[192:] == old[192:] and raw[12:184] == old[12:184]
+    h = 0xcbf29ce484222325
+    for b in raw[:184] + raw[192:]:
+        h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    assert struct.unpack_from("<Q", raw, 184)[0] == h
+    with glp.CircuitFile(os.path.join(GOLDEN, "zkdsa_2_3_v2.glpc")) as cf:
+        _same(cf.desc, synth.zkdsa_circuit(3))
+
+
 def test_damaged_files_are_errors(tmp_path):
     desc = synth.arith_circuit(5, synth.Config.standard_recursion_config(), seed=2)
     path = str(tmp_path / "c.glpc")

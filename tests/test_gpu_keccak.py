@@ -134,6 +134,8 @@ def test_keccak_config_proof_bytes(ctx, oracle):
     g0 = glp.Circuit(ctx, synth.zkdsa_circuit(3))
     p0 = g0.prove()
     d0 = g0.proof_to_bytes(p0)
+    oc = oracle.OracleCircuit(desc)
+    assert data == oc.proof_to_bytes(proof)        # oracle/gl_proof_bytes.c: the independent restatement of the Rust writer (25-byte digests)
     # count digests from the layout: every 32-byte digest of the Poseidon encoding shrinks by 7 bytes
     ndig = (len(d0) - len(data)) // 7
     assert (len(d0) - len(data)) % 7 == 0 and ndig > 3 * (1 << desc.cap_height)

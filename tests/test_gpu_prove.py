@@ -315,6 +315,24 @@ def test_proof_bytes_roundtrip(ctx, oracle):
         gc.proof_from_bytes(bytes(bad))
 
 
+@pytest.mark.parametrize("which", ["arith_rec", "ecdsa", "zkdsa", "poseidon_chain"])
+def test_proof_bytes_equal_the_oracle_serializer(ctx, oracle, which):
+    """glp_proof_to_bytes against oracle/gl_proof_bytes.c -- an independent restatement of `Buffer::write_proof_with_public_inputs`
+    that follows the Rust writer's call tree instead of the product's flat piece list -- byte for byte, on circuits with
+    different column counts, FRI arities and public-input counts.  Both are RECALLED from plonky2 0.1.4 (the reference holds no
+    proof bytes): agreement is self-consistency, parity with the fork stays unpinned."""
+    desc = {"arith_rec": lambda: synth.arith_circuit(9, synth.Config.standard_recursion_config(), seed=21, public_inputs=(5, 6, 7)),
+            "ecdsa": lambda: synth.ecdsa_shape_circuit(7, seed=4), "zkdsa": lambda: synth.zkdsa_circuit(3),
+            "poseidon_chain": lambda: synth.poseidon_chain_circuit(5)}[which]()
+    gc = glp.Circuit(ctx, desc)
+    oc = oracle.OracleCircuit(desc)
+    words = gc.prove()
+    data = gc.proof_to_bytes(words)
+    assert data == oc.proof_to_bytes(words)
+    assert (gc.proof_from_bytes(oc.proof_to_bytes(words)) == words).all()
+    gc.free()
+
+
 def test_malformed_gate_shapes_are_rejected_on_the_host(ctx):
     """A description whose gates would read past the wire columns must fail in glp_circuit_create, not on the GPU."""
     desc = synth.ecdsa_shape_circuit(7)

@@ -117,3 +117,53 @@ def test_headline_shape_2_16(ctx, oracle):
     assert gc.verify(gc.prove_device(dptr))
     ctx.dev_free(dptr)
     gc.free()
+
+
+@pytest.mark.parametrize("family", ["ecdsa", "zkdsa", "keccak"])
+def test_staged_witness_routed_columns_only(ctx, oracle, family):
+    """glp_witness_stage(GLP_WITNESS_ROUTED_ONLY) + glp_prove_staged: only the routed columns cross PCIe (from page-locked host
+    memory, on the copy stream), the advice columns are zero-filled and derived on the GPU.  The proof must be word for word the
+    proof of the witness the ORACLE's generators derive from the same routed columns, both verifiers accept it, and a complete
+    staged witness (all columns) gives glp_prove's proof."""
+    desc = FAMILIES[family]()
+    oc = oracle.OracleCircuit(desc)
+    gc = glp.Circuit(ctx, desc)
+    nr, n = desc.num_routed_wires, 1 << desc.degree_bits
+    pinned = ctx.host_alloc((nr, n))
+    pinned[:] = desc.wires[:nr]
+    st = gc.stage_witness(pinned, routed_only=True)
+    st2 = gc.stage_witness(pinned, routed_only=True)          # two uploads in flight, as in a pipeline
+    proof = gc.prove_staged(st)
+    assert (gc.prove_staged(st2) == proof).all()
+    st.free(); st2.free()
+    w0 = desc.wires.copy()
+    w0[nr:] = 0
+    want_w = oc.witness_fill(w0, only_advice=True)
+    rc, ref = oc.prove(wires=want_w)
+    assert rc == 0 and (proof == ref).all(), "first mismatch at word %d" % int(np.argmax(proof != ref))
+    if (want_w == desc.wires).all():                           # every advice wire of this witness is generated or zero
+        assert gc.verify(proof) and oc.verify(proof) == 0
+    full = gc.stage_witness(np.ascontiguousarray(desc.wires))  # pageable host memory, every column
+    assert (gc.prove_staged(full) == gc.prove()).all()
+    full.free()
+    with pytest.raises(glp.GlpError):
+        gc.stage_witness(pinned[: nr - 1], routed_only=True)
+    ctx.host_free(pinned)
+    gc.free()
+
+
+def test_staged_witness_real_secp256k1_circuit(ctx, oracle):
+    """The real one-signature circuit (2^17 rows): 80 of 136 columns uploaded, 56 derived on the GPU -- the same proof words as from
+    the complete host witness (every advice wire of the reference's generators is row-local)."""
+    from plonky2_lib_amd import gadgets_ecdsa as E
+    c = E.ecdsa_circuit(E.random_signatures(1, seed=5))
+    gc = glp.Circuit(ctx, c)
+    want = gc.prove()
+    pinned = ctx.host_alloc((c.num_routed_wires, 1 << c.degree_bits))
+    pinned[:] = c.wires[:c.num_routed_wires]
+    st = gc.stage_witness(pinned, routed_only=True)
+    got = gc.prove_staged(st)
+    st.free()
+    ctx.host_free(pinned)
+    assert (got == want).all() and gc.verify(got)
+    gc.free()

@@ -134,3 +134,35 @@ def test_smt_shape_circuit(oracle):
     w = c.wires.copy(); w[13, 4] = np.uint64((int(w[13, 4]) + 1) % oracle.P)      # a Poseidon output
     rc, bad = oc.prove(wires=w)
     assert oc.verify(bad) == 3
+
+
+@pytest.mark.parametrize("hasher", [0, 1])
+def test_proof_bytes_follow_the_buffer_layout(oracle, hasher):
+    """oracle/gl_proof_bytes.c (`ProofWithPublicInputs::to_bytes()` along the Rust writer's call tree; recalled, unpinned): byte count from
+    the struct sizes, little-endian field elements, one length byte in front of every Merkle path, 25-byte digests under KeccakHash<25>."""
+    c = synth.zkdsa_circuit(3)
+    c.hasher, c.circuit_digest = hasher, None
+    oc = oracle.OracleCircuit(c)
+    rc, proof = oc.prove()
+    assert rc == 0
+    data = oc.proof_to_bytes(proof)
+    nch, capn, nred = c.num_challenges, 1 << c.cap_height, len(c.reduction_arity_bits)
+    cols = [c.num_constants + c.num_routed_wires, c.num_wires, nch * (1 + c.num_partial_products), nch * c.quotient_degree_factor]
+    nopen = sum(cols) + nch
+    depth0 = c.degree_bits + c.rate_bits - c.cap_height
+    dig = 25 if hasher else 32
+    lg, steps = c.degree_bits + c.rate_bits, 0
+    for ab in c.reduction_arity_bits:
+        lg -= ab
+        steps += 16 * (1 << ab) + 1 + dig * (lg - c.cap_height)
+    per_query = sum(8 * k + 1 + dig * depth0 for k in cols) + steps
+    final_len = 1 << (c.degree_bits - sum(c.reduction_arity_bits))
+    want = dig * capn * (3 + nred) + 16 * nopen + c.num_query_rounds * per_query + 16 * final_len + 8 + 8 * len(c.public_inputs)
+    assert len(data) == want
+    assert data[:dig] == b"".join(int(w).to_bytes(8, "little") for w in proof[:4])[:dig]            # wires_cap[0]
+    o = dig * capn * 3
+    assert data[o:o + 16] == int(proof[12 * capn]).to_bytes(8, "little") + int(proof[12 * capn + 1]).to_bytes(8, "little")   # openings.constants[0]
+    q0 = dig * capn * (3 + nred) + 16 * nopen                                                       # first query round
+    assert data[q0 + 8 * cols[0]] == depth0                                                          # its first path's length byte
+    assert data[-8 * len(c.public_inputs):] == b"".join(int(v).to_bytes(8, "little") for v in c.public_inputs)
+    assert data[-8 * len(c.public_inputs) - 8:-8 * len(c.public_inputs)] == int(proof[-len(c.public_inputs) - 1]).to_bytes(8, "little")   # pow_witness

@@ -357,6 +357,20 @@ GLP_API int glp_verify(const glp_circuit *circuit, const uint64_t *proof_words);
  * unknown provenance; a wrong length is GLP_ERR_ARG, not a read past the buffer. */
 GLP_API int glp_verify_n(const glp_circuit *circuit, const uint64_t *proof_words, size_t num_words);
 
+/* `data.verify(proof)` for K proofs of one circuit, the query rounds on the GPU (a verifier for batch
+ * self-checking behind glp_prove_batch; the reference proves and then verifies every proof [REF src/zkdsa/circuits/mod.rs:341-347,
+ * src/ecdsa/gadgets/ecdsa.rs:349-352]).  Per proof, host threads run the transcript, the proof-of-work check and the
+ * vanishing-polynomial identity at zeta; every FRI query round of every proof (Merkle paths of the four initial oracles and of each
+ * commit-phase layer, `fri_combine_initial`, the arity-2^k consistency checks, the final polynomial) is one device launch over
+ * K x num_query_rounds 16-lane groups.  Accepts and rejects exactly what glp_verify does, with the same reason.
+ *   proofs       [K][glp_proof_words(circuit)], host memory
+ *   status_out   [K]: GLP_OK = accepted, GLP_ERR_PROVE = rejected
+ *   reasons_out  NULL, or [K][GLP_REASON_LEN] chars: the rejection reason of proof k (empty string if accepted)
+ * Returns GLP_OK when the batch was checked (whatever the verdicts), an error code for bad arguments / HIP failures. */
+#define GLP_REASON_LEN 160
+GLP_API int glp_verify_batch(glp_ctx *ctx, const glp_circuit *circuit, uint32_t num_proofs, const uint64_t *proofs, int32_t *status_out,
+                             char *reasons_out);
+
 /* plonky2 `ProofWithPublicInputs::to_bytes()` (util/serialization.rs `Buffer::write_proof_with_public_inputs`):
  * every field element as 8 little-endian bytes in the word order above, plus the one-byte sibling
  * count that `write_merkle_proof` puts in front of every Merkle path.  This is the wire format the

@@ -131,6 +131,7 @@ def load_library():
         "glp_verify": [vp, vp],
         "glp_verify_n": [vp, vp, sz],
         "glp_prove_batch": [vp, vp, u32, vp, C.c_int, vp, vp],
+        "glp_verify_batch": [vp, vp, u32, vp, vp, vp],
         "glp_witness_fill": [vp, vp, vp, C.c_int],
         "glp_witness_columns": [vp, u32, vp],
         "glp_host_alloc": [vp, sz, C.POINTER(vp)],
@@ -572,6 +573,21 @@ class Circuit:
         if rc == -5:          # GLP_ERR_PROVE: a well-formed call, the proof is rejected
             return False
         _chk(rc)
+
+    def verify_batch(self, proofs, reasons=False):
+        """glp_verify_batch: proofs [K][proof_words] -> bool array [K] (and the list of rejection reasons if asked); the query
+        rounds of all proofs run in one launch on the GPU."""
+        a = _a(proofs)
+        if a.ndim != 2 or a.shape[1] != self.proof_words:
+            raise GlpError(-1, "proofs must be [K][proof_words]")
+        K = a.shape[0]
+        status = np.zeros(K, np.int32)
+        buf = C.create_string_buffer(K * 160) if reasons else None
+        _chk(load_library().glp_verify_batch(self.ctx._h, self._h, K, _p(a), status.ctypes.data_as(C.c_void_p), buf))
+        ok = status == 0
+        if reasons:
+            return ok, [buf.raw[160 * k:160 * (k + 1)].split(b"\0", 1)[0].decode() for k in range(K)]
+        return ok
 
     def proof_to_bytes(self, proof_words):
         """`ProofWithPublicInputs::to_bytes()`."""

@@ -9,6 +9,8 @@
 // host, like the transcript, and touches no device memory (the circuit handle supplies the gate table, the coset
 // shifts, the digest and the constants/sigmas cap).  It shares no code with the CPU checker the tests use: the two
 // verifiers and the two provers are cross-checked against each other in tests/test_gpu_prove.py.
+#include <string>
+#include "merkle.h"
 #include "prover_types.h"
 
 namespace {
@@ -263,7 +265,15 @@ bool merkle_ok(int hasher, const u64 *leaf, size_t ncols, size_t index, const u6
     return memcmp(cur, cap + 4 * index, 32) == 0;
 }
 
-int verify_impl(const glp_circuit *cc, const u64 *proof) {
+// What the transcript yields for the FRI half of the verification (fri/verifier.rs): challenges, the reduced openings and the
+// query indices.  verify_front fills it (canonical-form check, plonk/get_challenges.rs, proof of work, the vanishing-polynomial
+// identity at zeta); the query rounds then run on the host (verify_fri_host: glp_verify) or on the device (glp_verify_batch).
+struct VChal {
+    E zeta, zeta_next, fri_alpha, red0, red1, shift1;
+    std::vector<E> fri_betas;
+    std::vector<u64> x_index;
+};
+int verify_front(const glp_circuit *cc, const u64 *proof, VChal &vc) {
     const glp_circuit_desc &d = cc->d;
     const Layout &L = cc->L;
     const int lg = (int)d.degree_bits, rb = (int)d.rate_bits, lgN = lg + rb;
@@ -375,7 +385,7 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
         }
     }
 
-    // ---- FRI (fri/verifier.rs)
+    // ---- FRI (fri/verifier.rs): reduced openings and query indices
     const E zeta_next = zeta * root_of_unity(lg);
     E red0 = ZERO, red1 = ZERO;            // PrecomputedReducedOpenings
     {
@@ -387,19 +397,49 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
         ap = ONE;
         for (size_t j = 0; j < nch; j++) { red1 = red1 + ap * rd(p_zn + 2 * j); ap = ap * fri_alpha; }
     }
+    vc.zeta = zeta; vc.zeta_next = zeta_next; vc.fri_alpha = fri_alpha; vc.red0 = red0; vc.red1 = red1;
+    vc.shift1 = epow(fri_alpha, nch);
+    vc.fri_betas = fri_betas;
+    vc.x_index.resize(d.num_query_rounds);
+    for (u32 q = 0; q < d.num_query_rounds; q++) vc.x_index[q] = ch.get() % (u64)N;
+    (void)lgN;
+#undef FAIL
+    return GLP_OK;
+}
+
+// messages of the query rounds, shared by the host and the device path (code: see k_verify_queries)
+int query_failure(u32 q, u32 code, u32 nred) {
+    if (code >= 1 && code <= 4) return set_error(GLP_ERR_PROVE, "Invalid Merkle proof (query %u, initial tree %d)", q, (int)code - 1);
+    if (code == 5) return set_error(GLP_ERR_PROVE, "query point equals an opening point");
+    if (code >= 6 && code < 6 + 2 * nred) {
+        const u32 r = (code - 6) / 2;
+        if ((code - 6) % 2 == 0) return set_error(GLP_ERR_PROVE, "FRI consistency check failed (query %u, reduction %u)", q, r);
+        return set_error(GLP_ERR_PROVE, "Invalid Merkle proof (query %u, reduction %u)", q, r);
+    }
+    return set_error(GLP_ERR_PROVE, "Final polynomial evaluation is invalid (query %u)", q);
+}
+
+int verify_fri_host(const glp_circuit *cc, const u64 *proof, const VChal &vc) {
+    const glp_circuit_desc &d = cc->d;
+    const Layout &L = cc->L;
+    const int lg = (int)d.degree_bits, rb = (int)d.rate_bits, lgN = lg + rb;
+    const u32 nch = d.num_challenges, capn = 1u << d.cap_height, nred = d.num_reductions;
+    const E zeta = vc.zeta, zeta_next = vc.zeta_next, fri_alpha = vc.fri_alpha, red0 = vc.red0, red1 = vc.red1, shift1 = vc.shift1;
+    const std::vector<E> &fri_betas = vc.fri_betas;
+#define FAIL(CODE) return query_failure(q, (CODE), nred)
     const u64 *caps4[4] = {cc->cs_cap.data(), proof + L.caps, proof + L.caps + capn * 4, proof + L.caps + 2 * capn * 4};
     size_t cols_total = 0;
     for (int k = 0; k < 4; k++) cols_total += L.oracle_cols[k];
-    const E shift0 = epow(fri_alpha, cols_total), shift1 = epow(fri_alpha, nch);
+    const E shift0 = epow(fri_alpha, cols_total);
     const u64 wN = root_of_unity(lgN);
     for (u32 q = 0; q < d.num_query_rounds; q++) {
-        size_t x_index = (size_t)(ch.get() % (u64)N);
+        size_t x_index = (size_t)vc.x_index[q];
         const u64 *w = proof + L.queries + (size_t)q * L.query_stride;
         const u64 *evals[4];
         for (int k = 0; k < 4; k++) {
             evals[k] = w;
             if (!merkle_ok((int)d.hasher, w, L.oracle_cols[k], x_index, caps4[k], w + L.oracle_cols[k], L.depth0))
-                FAIL("Invalid Merkle proof (query %u, initial tree %d)", q, k);
+                FAIL(1 + (u32)k);
             w += L.oracle_cols[k] + 4 * (size_t)L.depth0;
         }
         u64 subgroup_x = mul(GEN, pow(wN, (u64)brev(x_index, lgN)));
@@ -412,7 +452,7 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
             ap = ONE;
             for (u32 j = 0; j < nch; j++) { r1 = r1 + ap * evals[2][j]; ap = ap * fri_alpha; }
             const E sx((u64)subgroup_x);
-            if (sx == zeta || sx == zeta_next) FAIL("query point equals an opening point");
+            if (sx == zeta || sx == zeta_next) FAIL(5);
             E sum = ZERO;
             sum = sum * shift0 + (r0 - red0) * inv(sx - zeta);
             sum = sum * shift1 + (r1 - red1) * inv(sx - zeta_next);
@@ -422,7 +462,7 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
             const u32 ab = d.reduction_arity_bits[r], arity = 1u << ab;
             const u64 *ev = w, *path = w + 2 * arity;
             const size_t coset_index = x_index >> ab, within = x_index & (arity - 1);
-            if (!(rd(ev + 2 * within) == old_eval)) FAIL("FRI consistency check failed (query %u, reduction %u)", q, r);
+            if (!(rd(ev + 2 * within) == old_eval)) FAIL(6 + 2 * r);
             {   // compute_evaluation: interpolate the coset and evaluate at beta
                 const u64 gA = root_of_unity((int)ab);
                 const u64 coset_start = mul(subgroup_x, pow(gA, (u64)(arity - brev(within, (int)ab))));
@@ -443,19 +483,268 @@ int verify_impl(const glp_circuit *cc, const u64 *proof) {
                 old_eval = acc;
             }
             if (!merkle_ok((int)d.hasher, ev, 2 * (size_t)arity, coset_index, proof + L.fri_caps + (size_t)r * capn * 4, path, L.step_depth[r]))
-                FAIL("Invalid Merkle proof (query %u, reduction %u)", q, r);
+                FAIL(7 + 2 * r);
             for (u32 i = 0; i < ab; i++) subgroup_x = sqr(subgroup_x);
             x_index = coset_index;
             w += 2 * (size_t)arity + 4 * (size_t)L.step_depth[r];
         }
         E acc = ZERO;       // final_poly.eval(subgroup_x)
         for (u32 i = L.final_len; i-- > 0;) acc = acc * (u64)subgroup_x + rd(proof + L.final_poly + 2 * (size_t)i);
-        if (!(acc == old_eval)) FAIL("Final polynomial evaluation is invalid (query %u)", q);
+        if (!(acc == old_eval)) FAIL(6 + 2 * nred);
     }
 #undef FAIL
     return GLP_OK;
 }
+int verify_impl(const glp_circuit *cc, const u64 *proof) {
+    VChal vc;
+    GLP_TRY(verify_front(cc, proof, vc));
+    return verify_fri_host(cc, proof, vc);
+}
 }  // namespace
+
+// ------------------------------------------------------------------------------------------ query rounds on the device
+// glp_verify_batch (a GPU verifier for batch self-checking; every reference driver proves and then
+// verifies [REF src/zkdsa/circuits/mod.rs:341-347, src/ecdsa/gadgets/ecdsa.rs:349-352]).  Per proof the transcript, the proof of
+// work and the one constraint evaluation at zeta stay on host threads (verify_front: a few dozen permutations); the query
+// rounds -- K x num_query_rounds independent checks, each a few dozen to a few hundred permutations (Merkle paths of the four
+// initial oracles and of every FRI layer), `fri_combine_initial`, the arity-2^k interpolations and the final polynomial -- are
+// one launch: a 16-lane group per (proof, query), hashes in the 12-lane cooperative form (poseidon.h permute_coop: ~5x lower
+// latency per hash than one state per lane, which is what matters for a chain of dependent hashes), the alpha-combination and
+// the Lagrange terms spread over the lanes of the group.
+namespace {
+constexpr u32 VC_ALPHA = 0, VC_ZETA = 2, VC_ZETA_NEXT = 4, VC_RED0 = 6, VC_RED1 = 8, VC_SHIFT1 = 10, VC_BETAS = 12, VC_XIDX = 44;
+struct VQArgs {
+    const u64 *proofs;      // [K][total]
+    const u64 *vchal;       // [K][vstride]: fri_alpha, zeta, zeta_next, red0, red1, alpha^nch, betas[16] (ext each), x_index[nq]
+    const u64 *cs_cap;      // [2^cap_height][4]
+    u32 *status;            // [K][nq]: 0 = accepted, else the code query_failure() turns into the verifier's message
+    size_t total, caps, fri_caps, queries, query_stride, final_poly;
+    u32 vstride, nq, K, nch, lgN, cap_height, depth0, nred, final_len;
+    u32 oracle_cols[4], ab[16], step_depth[16];
+    u64 wN, gA[16];         // root_of_unity(lgN), root_of_unity(ab[r])
+};
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    const u32 lo = (u32)__shfl((int)(u32)v, src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
+    const u32 lo = (u32)__shfl_xor((int)(u32)v, m, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ ext2 group_sum(ext2 v) {         // sum over the 16 lanes of a group, result on every lane
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v = e_add(v, e_make(shfl_xor64(v.a, m), shfl_xor64(v.b, m)));
+    return v;
+}
+__device__ __forceinline__ u32 group_or(u32 v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v |= (u32)__shfl_xor((int)v, m, 64);
+    return v;
+}
+__device__ __forceinline__ u64 dvpow(u64 b, u64 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = mul(r, b); b = sqr(b); e >>= 1; }
+    return r;
+}
+// verify_merkle_proof_to_cap on one 16-lane group: true (on every lane of the group) if the leaf does NOT hash to the cap entry.
+// Every lane of the wave must call it (shuffles); len, depth are the same for all groups of a launch.
+template <int HASHER>
+__device__ __forceinline__ bool merkle_bad(const u64 *leaf, u32 len, size_t index, const u64 *path, u32 depth, const u64 *cap, int l, int gb) {
+    u32 bad = 0;
+    if (HASHER == GLP_HASH_KECCAK25) {
+        if (l == 0) {                                     // Keccak is 64-bit logic at full rate: one lane walks the path
+            u64 cur[4] = {0, 0, 0, 0};
+            if (8 * len <= 25) { for (u32 i = 0; i < len; i++) cur[i] = leaf[i]; }
+            else {
+                kec::Sponge sp;
+                kec::sponge_init(sp);
+                for (u32 i = 0; i < len; i++) kec::sponge_absorb(sp, leaf[i]);
+                kec::sponge_finish(sp);
+                kec::sponge_digest25(sp, cur);
+            }
+            for (u32 dd = 0; dd < depth; dd++) {
+                u64 nxt[4];
+                if (index & 1) kec::two_to_one(path + 4 * dd, cur, nxt); else kec::two_to_one(cur, path + 4 * dd, nxt);
+                cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2]; cur[3] = nxt[3];
+                index >>= 1;
+            }
+            for (int i = 0; i < 4; i++) bad |= cur[i] != cap[4 * index + i];
+        }
+    } else {
+        u64 x = 0;
+        if (len <= 4) x = (u32)l < len ? leaf[l] : 0;     // hash_or_noop: copied, zero padded
+        else
+            for (u32 c0 = 0; c0 < len; c0 += 8) {         // sponge, overwrite mode: lanes past the chunk keep their state
+                if (l < 8 && c0 + (u32)l < len) x = leaf[c0 + l];
+                x = pos::permute_coop(x, l, gb);
+            }
+        for (u32 dd = 0; dd < depth; dd++) {              // two_to_one(left, right) = permute(left || right || 0000)[0..4]
+            const u64 sib = path[4 * dd + (l & 3)];
+            const u64 cur = shfl64(x, gb + (l & 3));
+            const bool right = index & 1;
+            u64 nx = 0;
+            if (l < 4) nx = right ? sib : cur; else if (l < 8) nx = right ? cur : sib;
+            x = pos::permute_coop(nx, l, gb);
+            index >>= 1;
+        }
+        if (l < 4) bad = x != cap[4 * index + l];
+    }
+    return group_or(bad) != 0;
+}
+__device__ __forceinline__ ext2 rd2(const u64 *p) { return e_make(p[0], p[1]); }
+
+template <int HASHER>
+__global__ __launch_bounds__(256) void k_verify_queries(VQArgs a) {
+    const int tid = threadIdx.x, l = tid & 15, lane = tid & 63, gb = lane & ~15;
+    const size_t grp0 = (size_t)blockIdx.x * 16 + (tid >> 4), ngrp = (size_t)a.K * a.nq;
+    const bool live = grp0 < ngrp;
+    const size_t grp = live ? grp0 : 0;                   // idle groups redo group 0 (the shuffles need every lane) and write nothing
+    const u32 k = (u32)(grp / a.nq), q = (u32)(grp % a.nq);
+    const u64 *proof = a.proofs + (size_t)k * a.total, *vc = a.vchal + (size_t)k * a.vstride;
+    const u64 *w = proof + a.queries + (size_t)q * a.query_stride;
+    size_t x_index = (size_t)vc[VC_XIDX + q];
+    const ext2 alpha = rd2(vc + VC_ALPHA), zeta = rd2(vc + VC_ZETA), zeta_next = rd2(vc + VC_ZETA_NEXT);
+    const u32 capn4 = 4u << a.cap_height;
+    u32 code = 0;
+#define VQ_FAIL(C) do { if (code == 0) code = (C); } while (0)
+    // ---- initial trees; sum_j alpha^j evals_j over the four oracles in order (batch 0) and the Z columns (batch 1)
+    ext2 a16 = alpha;
+#pragma unroll
+    for (int i = 0; i < 4; i++) a16 = e_sqr(a16);
+    const ext2 al = e_pow(alpha, (u64)l);
+    ext2 r0 = e_from(0), r1 = e_from(0), off = e_from(1);
+    for (int t = 0; t < 4; t++) {
+        const u32 ncols = a.oracle_cols[t];
+        const u64 *cap = t == 0 ? a.cs_cap : proof + a.caps + (size_t)(t - 1) * capn4;
+        if (merkle_bad<HASHER>(w, ncols, x_index, w + ncols, a.depth0, cap, l, gb)) VQ_FAIL(1 + (u32)t);
+        ext2 part = e_from(0);                            // lane l: sum_i evals[l + 16 i] (alpha^16)^i, Horner from the top
+        if ((u32)l < ncols)
+            for (int j = (int)(((ncols - 1 - (u32)l) >> 4) << 4) + l; j >= 0; j -= 16) part = e_add(e_mul(part, a16), e_from(w[j]));
+        r0 = e_add(r0, e_mul(off, group_sum(e_mul(part, al))));
+        off = e_mul(off, e_pow(alpha, (u64)ncols));
+        if (t == 2) { ext2 ap = e_from(1); for (u32 j = 0; j < a.nch; j++) { r1 = e_add(r1, e_scale(ap, w[j])); ap = e_mul(ap, alpha); } }
+        w += ncols + 4 * (size_t)a.depth0;
+    }
+    u64 subgroup_x = mul(GEN, dvpow(a.wN, (u64)(__brevll((unsigned long long)x_index) >> (64 - a.lgN))));
+    ext2 old_eval;
+    {
+        const ext2 d0 = e_sub(e_from(subgroup_x), zeta), d1 = e_sub(e_from(subgroup_x), zeta_next);
+        if ((d0.a == 0 && d0.b == 0) || (d1.a == 0 && d1.b == 0)) VQ_FAIL(5);
+        ext2 sum = e_mul(e_sub(r0, rd2(vc + VC_RED0)), e_inv(d0));
+        sum = e_add(e_mul(sum, rd2(vc + VC_SHIFT1)), e_mul(e_sub(r1, rd2(vc + VC_RED1)), e_inv(d1)));
+        old_eval = sum;
+    }
+    // ---- reductions: consistency with the previous layer, interpolation of the coset at beta, Merkle path of the layer
+    for (u32 r = 0; r < a.nred; r++) {
+        const u32 ab = a.ab[r], arity = 1u << ab;
+        const u64 *ev = w, *path = w + 2 * (size_t)arity;
+        const size_t coset_index = x_index >> ab, within = x_index & (arity - 1);
+        if (!e_eq(rd2(ev + 2 * within), old_eval)) VQ_FAIL(6 + 2 * r);
+        {   // compute_evaluation: sum_i vals_i prod_{j != i} (beta - p_j) / (p_i - p_j), p_j = coset_start gA^j; lane l takes i = l, l + 16
+            const u64 gA = a.gA[r];
+            const u32 rw = (u32)(__brev((unsigned)within) >> (32 - ab));
+            const u64 coset_start = mul(subgroup_x, dvpow(gA, (u64)(arity - rw)));
+            const ext2 beta = rd2(vc + VC_BETAS + 2 * r);
+            ext2 acc = e_from(0);
+            for (u32 i = (u32)l; i < arity; i += 16) {
+                const u64 pi = mul(coset_start, dvpow(gA, (u64)i));
+                ext2 num = e_from(1);
+                u64 den = 1, pj = coset_start;
+                for (u32 j = 0; j < arity; j++) {
+                    if (j != i) { num = e_mul(num, e_sub(beta, e_from(pj))); den = mul(den, sub(pi, pj)); }
+                    pj = mul(pj, gA);
+                }
+                const u32 bi = (u32)(__brev((unsigned)i) >> (32 - ab));                   // reverse_index_bits(evals)
+                acc = e_add(acc, e_scale(e_mul(rd2(ev + 2 * bi), num), glf::inv(den)));
+            }
+            old_eval = group_sum(acc);
+        }
+        const u64 *cap = proof + a.fri_caps + (size_t)r * capn4;
+        if (merkle_bad<HASHER>(ev, 2 * arity, coset_index, path, a.step_depth[r], cap, l, gb)) VQ_FAIL(7 + 2 * r);
+        for (u32 i = 0; i < ab; i++) subgroup_x = sqr(subgroup_x);
+        x_index = coset_index;
+        w += 2 * (size_t)arity + 4 * (size_t)a.step_depth[r];
+    }
+    {   // final_poly.eval(subgroup_x)
+        ext2 acc = e_from(0);
+        for (u32 i = a.final_len; i-- > 0;) acc = e_add(e_scale(acc, subgroup_x), rd2(proof + a.final_poly + 2 * (size_t)i));
+        if (!e_eq(acc, old_eval)) VQ_FAIL(6 + 2 * a.nred);
+    }
+#undef VQ_FAIL
+    if (live && l == 0) a.status[grp] = code;
+}
+}  // namespace
+
+#include "host_pool.h"
+extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, const uint64_t *proofs, int32_t *status_out, char *reasons_out) {
+    GLP_REQUIRE(c && cc && proofs && status_out, "null argument");
+    GLP_REQUIRE(cc->ctx == c, "circuit belongs to another context");
+    GLP_REQUIRE(K >= 1 && K <= 65536, "glp_verify_batch: batch of %u proofs outside 1..65536", K);
+    GLP_TRY(bind(c));
+    const glp_circuit_desc &d = cc->d;
+    const Layout &L = cc->L;
+    const u32 nq = d.num_query_rounds, nred = d.num_reductions;
+    const u32 vstride = (VC_XIDX + nq + 3) & ~3u;
+    std::vector<VChal> vcs(K);
+    std::vector<int> rc(K, GLP_OK);
+    std::vector<std::string> why(K);
+    std::vector<u64> hv((size_t)K * vstride, 0);
+    // host half, one proof per task on the context's pool: canonical form, transcript, proof of work, vanishing polynomial at zeta
+    ctx_host_pool(c).run(K, [&](size_t k) {
+        rc[k] = verify_front(cc, proofs + k * L.total, vcs[k]);
+        if (rc[k] != GLP_OK) { why[k] = g_last_error; return; }
+        const VChal &v = vcs[k];
+        u64 *o = &hv[k * vstride];
+        auto put = [&](u32 at, const E &e) { o[at] = e.v.a; o[at + 1] = e.v.b; };
+        put(VC_ALPHA, v.fri_alpha); put(VC_ZETA, v.zeta); put(VC_ZETA_NEXT, v.zeta_next); put(VC_RED0, v.red0); put(VC_RED1, v.red1); put(VC_SHIFT1, v.shift1);
+        for (u32 r = 0; r < nred; r++) put(VC_BETAS + 2 * r, v.fri_betas[r]);
+        for (u32 q = 0; q < nq; q++) o[VC_XIDX + q] = v.x_index[q];
+    });
+    // device half: every query round of every proof in one launch.  Proofs the host half already rejected still ride along
+    // (their slots hold zero challenges and every index is in range); their device status is ignored.
+    struct Scratch { glp_ctx *c; std::vector<void *> p; ~Scratch() { (void)hipStreamSynchronize(c->stream); for (void *q : p) c->release(q); } } sc{c, {}};
+    auto get = [&](void **p, size_t bytes) -> int { int r = c->alloc(p, bytes); if (r == GLP_OK) sc.p.push_back(*p); return r; };
+    u64 *dev_proofs = nullptr, *dev_vc = nullptr;
+    u32 *dev_status = nullptr;
+    GLP_TRY(get((void **)&dev_proofs, (size_t)K * L.total * 8));
+    GLP_TRY(get((void **)&dev_vc, hv.size() * 8));
+    GLP_TRY(get((void **)&dev_status, (size_t)K * nq * 4));
+    GLP_HIP(hipMemcpyAsync(dev_proofs, proofs, (size_t)K * L.total * 8, hipMemcpyHostToDevice, c->stream));
+    GLP_HIP(hipMemcpyAsync(dev_vc, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
+    VQArgs a;
+    memset(&a, 0, sizeof(a));
+    a.proofs = dev_proofs; a.vchal = dev_vc; a.status = dev_status;
+    const size_t N = (size_t)1 << (d.degree_bits + d.rate_bits);
+    a.cs_cap = cc->cs->digests + 4 * merkle_cap_offset(N, (int)d.cap_height);
+    a.total = L.total; a.caps = L.caps; a.fri_caps = L.fri_caps; a.queries = L.queries; a.query_stride = L.query_stride; a.final_poly = L.final_poly;
+    a.vstride = vstride; a.nq = nq; a.K = K; a.nch = d.num_challenges; a.lgN = d.degree_bits + d.rate_bits; a.cap_height = d.cap_height;
+    a.depth0 = L.depth0; a.nred = nred; a.final_len = L.final_len;
+    for (int t = 0; t < 4; t++) a.oracle_cols[t] = L.oracle_cols[t];
+    for (u32 r = 0; r < nred; r++) { a.ab[r] = d.reduction_arity_bits[r]; a.step_depth[r] = L.step_depth[r]; a.gA[r] = root_of_unity((int)d.reduction_arity_bits[r]); }
+    a.wN = root_of_unity((int)a.lgN);
+    {
+        StageScope st(c, "verify_queries", 8.0 * K * L.total);
+        const unsigned nblocks = (unsigned)(((size_t)K * nq + 15) / 16);
+        if (d.hasher == GLP_HASH_KECCAK25) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_queries<GLP_HASH_KECCAK25>), dim3(nblocks), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_verify_queries<GLP_HASH_POSEIDON>), dim3(nblocks), dim3(256), 0, c->stream, a);
+        GLP_HIP(hipGetLastError());
+    }
+    std::vector<u32> hs((size_t)K * nq);
+    GLP_HIP(hipMemcpyAsync(hs.data(), dev_status, hs.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    GLP_HIP(hipStreamSynchronize(c->stream));
+    for (u32 k = 0; k < K; k++) {
+        if (rc[k] == GLP_OK)
+            for (u32 q = 0; q < nq && rc[k] == GLP_OK; q++)
+                if (hs[(size_t)k * nq + q]) { rc[k] = query_failure(q, hs[(size_t)k * nq + q], nred); why[k] = g_last_error; }
+        status_out[k] = rc[k];
+        if (reasons_out) {
+            char *o = reasons_out + (size_t)k * GLP_REASON_LEN;
+            memset(o, 0, GLP_REASON_LEN);
+            if (rc[k] != GLP_OK) strncpy(o, why[k].c_str(), GLP_REASON_LEN - 1);
+        }
+    }
+    return GLP_OK;
+}
 
 extern "C" int glp_verify(const glp_circuit *cc, const uint64_t *proof_words) {
     GLP_REQUIRE(cc && proof_words, "null argument");

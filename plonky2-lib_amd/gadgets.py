@@ -361,7 +361,10 @@ class GadgetBuilder:
         poseidon_rows = self._poseidon_rows
         nrows = len(self.rows)
         log_n = max(min_log_n, 2, (nrows - 1).bit_length())
-        b = synth.Builder(cfg, log_n, seed=0, random_from_row=nrows)
+        # padding rows (NoopGate) stay all-zero, as in plonky2, where `PartitionWitness::full_witness` leaves every unset wire at zero:
+        # then each advice wire of the witness is either a row-local generator's output or zero, which is what lets the routed
+        # columns alone reproduce the whole witness on the GPU (glp_witness_stage with GLP_WITNESS_ROUTED_ONLY)
+        b = synth.Builder(cfg, log_n, seed=0, random_from_row=1 << log_n)
         by_kind = {}
         for r, (g, p0, p1, consts) in enumerate(self.rows):
             by_kind.setdefault((g, p0, p1), []).append(r)

@@ -61,6 +61,8 @@ def parse():
                          "then a batch of that many proofs.  Default 1 keeps the per-stage timings free of overlap")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements after the timed region (host witness, two in flight, stand-in, perf.rs batch)")
     ap.add_argument("--no-perf-rs", action="store_true", help="skip variants.perf_rs_batch_20 (a 2^21-row circuit: ~40 s of host-side circuit building)")
+    ap.add_argument("--own-witness", action="store_true", help="ecdsa, several ranks: every rank builds its own circuit and witness in Python "
+                    "instead of mapping the hand-off file rank 0 writes")
     ap.add_argument("--dist-backend", default=None, help="override the torch.distributed backend (rehearsals: gloo)")
     ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: every rank uses this GPU")
     return ap.parse_args()
@@ -269,14 +271,19 @@ def pipelined_variant(glp, ctx, circuit, desc, device, resident_proof, np, steps
     def pipeline(c_ctx, c_circuit, count, sink):
         pinned = c_ctx.host_alloc((nr, n))
         pinned[:] = desc.wires[:nr]
+        # steady state before the clock starts: one proof done, the next witness already on its way
+        cur = c_circuit.stage_witness(pinned, routed_only=True)
+        nxt = c_circuit.stage_witness(pinned, routed_only=True)
+        c_circuit.prove_staged(cur)
+        cur.free()
         sink["filled"].set()
         sink["ready"].wait()
-        nxt = c_circuit.stage_witness(pinned, routed_only=True)
         for i in range(count):
-            cur, nxt = nxt, (c_circuit.stage_witness(pinned, routed_only=True) if i + 1 < count else None)
+            cur, nxt = nxt, c_circuit.stage_witness(pinned, routed_only=True)      # upload of proof i + 1 behind proof i
             sink["proof"] = c_circuit.prove_staged(cur)
             cur.free()
         c_ctx.synchronize()
+        nxt.free()
         sink["pinned"] = pinned
 
     def run(pipes, count):
@@ -286,7 +293,7 @@ def pipelined_variant(glp, ctx, circuit, desc, device, resident_proof, np, steps
         for t in th:
             t.start()
         for sk in sinks:
-            sk["filled"].wait()                             # the page-locked buffers are filled (host memcpy) before the clock starts
+            sk["filled"].wait()                             # buffers filled, pipelines primed (one proof each) before the clock starts
         t0 = time.perf_counter()
         go.set()
         for t in th:
@@ -296,11 +303,9 @@ def pipelined_variant(glp, ctx, circuit, desc, device, resident_proof, np, steps
             pc.host_free(sk["pinned"])
         return dt, sinks
 
-    run([(ctx, circuit)], 1)                                # warm-up: pool sizes for two staged witnesses
     dt1, s1 = run([(ctx, circuit)], steps)
     c2 = glp.Context(device)
     cc2 = glp.Circuit(c2, desc)
-    run([(ctx, circuit), (c2, cc2)], 1)
     dt2, s2 = run([(ctx, circuit), (c2, cc2)], steps)
     cc2.free()
     c2.close()
@@ -308,8 +313,9 @@ def pipelined_variant(glp, ctx, circuit, desc, device, resident_proof, np, steps
     return {"value": steps / dt1, "unit": "proofs/sec", "ms_per_proof": dt1 / steps * 1e3,
             "two_pipelines": {"value": 2 * steps / dt2, "unit": "proofs/sec"},
             "same_proof_as_resident": same, "uploaded_columns": nr, "derived_on_gpu_columns": int(desc.num_wires) - nr,
-            "note": "PCIe-inclusive: every proof starts in page-locked HOST memory; %d of %d columns uploaded (%.2f GB per proof) on the copy "
-                    "stream during the previous proof, the other %d derived in HBM by glp_witness_fill; not the headline value"
+            "note": "PCIe-inclusive, steady state of the pipeline (one proof primed before the clock): every proof starts in page-locked HOST "
+                    "memory; %d of %d columns uploaded (%.2f GB per proof) on the copy stream during the previous proof, the other %d derived "
+                    "in HBM by glp_witness_fill; not the headline value"
                     % (nr, int(desc.num_wires), nr * n * 8 / 1e9, int(desc.num_wires) - nr)}
 
 
@@ -538,14 +544,30 @@ def main():
     # (the reference's `builder.build()`) and witness generation are CPU work outside the timed region.
     real = a.circuit == "real" and lg >= 17
     nsig = 0
+    shared_file, cf = None, None
+    t_build = 0.0
     if real:
         from plonky2_lib_amd import gadgets_ecdsa
         nsig = ((1 << lg) - 7714 - 2) // 98687             # 98 687 rows per signature + 7 714 shared ConstantGate rows + PublicInputGate
-        t_build = time.perf_counter()
-        desc = gadgets_ecdsa.ecdsa_circuit(gadgets_ecdsa.random_signatures(nsig, seed=SEED + 1000 * rank), min_log_n=lg)
-        t_build = time.perf_counter() - t_build
-        if desc.degree_bits != lg:
-            raise SystemExit("bench.py: %d signatures gave 2^%d rows, expected 2^%d" % (nsig, desc.degree_bits, lg))
+        # Several ranks on one node: rank 0 builds the circuit (Python, ~17 s and ~7 GB at 2^20) and writes it ONCE as a circuit hand-off
+        # file (include/glp.h glp_circuit_file_*); the other ranks map that file instead of repeating the build.  --own-witness: every
+        # rank builds its own circuit + witness from its own signatures (what a single rank always does).
+        share = world > 1 and not a.own_witness
+
+        def build_circuit():
+            d = gadgets_ecdsa.ecdsa_circuit(gadgets_ecdsa.random_signatures(nsig, seed=SEED + 1000 * rank), min_log_n=lg)
+            if d.degree_bits != lg:
+                raise SystemExit("bench.py: %d signatures gave 2^%d rows, expected 2^%d" % (nsig, d.degree_bits, lg))
+            return d
+        if share:
+            import tempfile
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            shared_file = os.path.join(base, "glp_bench_%s_%d.glpc" % (os.environ.get("MASTER_PORT", "0"), lg))
+            desc, cf, t_build = gdist.shared_circuit(grp, build_circuit, shared_file, SEED)
+        else:
+            t_build = time.perf_counter()
+            desc = build_circuit()
+            t_build = time.perf_counter() - t_build
     else:
         desc = synth.ecdsa_shape_circuit(lg, seed=SEED + 1000 * rank)
     circuit = glp.Circuit(ctx, desc)
@@ -634,6 +656,9 @@ def main():
                         "the timed region; gate placement is not plonky2's); every signature is a valid random signature, a forged one cannot be "
                         "wired.  Rounds 1 and 2 timed a gate-mix stand-in of the same shape: variants.gate_mix_stand_in" % (nsig, t_build),
                 "parallelism": "independent proofs sharded one per GPU, no collective",
+                "circuit_hand_off": (("rank 0 built the circuit and wrote it once as %s (glp_circuit_file_write); ranks 1..%d mapped it and "
+                                      "proved it with rank-specific values in the unconstrained padding rows" % (os.path.basename(shared_file), world - 1))
+                                     if shared_file else "every rank built its own circuit and witness"),
                 "signatures_per_proof": nsig,
                 "proofs_in_flight_per_gpu": max(a.inflight, 1),
             } if real else {
@@ -766,6 +791,9 @@ def main():
         c2.close()
     circuit.free()
     ctx.close()
+    if cf is not None:
+        desc.wires = None
+        cf.close()
     grp.close()
 
 

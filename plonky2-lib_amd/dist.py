@@ -72,3 +72,38 @@ def timed_steps(group, step, steps, warmup, device_sync=lambda: None):
     device_sync()
     group.barrier()
     return group.max_over_ranks(time.perf_counter() - t0)
+
+
+def shared_circuit(group, build, path, seed):
+    """Several ranks on one node, one circuit: rank 0 calls build() (the expensive host-side circuit construction) and writes the
+    result ONCE as a circuit hand-off file (include/glp.h glp_circuit_file_*) at `path`; the other ranks map that file instead of
+    repeating the build.  Every rank still proves a witness of its own: NoopGate (padding) rows constrain nothing, so ranks > 0 put
+    rank-specific values (SplitMix64 of seed + 1000 rank) into the advice wires of those rows -- a valid witness of the same circuit,
+    a different proof.  Returns (desc, circuit_file_or_None, seconds rank 0 spent in build()); the caller closes the file after use.
+    The file's name is removed as soon as every rank has mapped it."""
+    import numpy as np
+    from . import binding as glp
+    cf, t_build = None, 0.0
+    if group.rank == 0:
+        import atexit
+        t0 = time.perf_counter()
+        desc = build()
+        t_build = time.perf_counter() - t0
+        atexit.register(lambda: os.path.exists(path) and os.unlink(path))          # also on an early exit
+        glp.write_circuit_file(path, desc, with_witness=True)
+    group.barrier()                                                             # the file is complete
+    if group.rank != 0:
+        cf = glp.CircuitFile(path, verify_checksum=False)      # mapped; the canonical-form scan of every section still runs
+        desc = cf.desc
+        w = np.array(desc.wires)
+        noops = [i for i, g in enumerate(desc.gates) if g["type"] == 0]
+        nadv = desc.num_wires - desc.num_routed_wires
+        if noops and nadv:
+            pad = np.nonzero(desc.constants[desc.gates[noops[0]]["selector_index"]] == np.uint64(noops[0]))[0]
+            if len(pad):
+                w[desc.num_routed_wires:, pad] = glp.splitmix_field(seed + 1000 * group.rank, nadv * len(pad)).reshape(nadv, len(pad))
+        desc.wires = w
+    group.barrier()                                                             # every rank has mapped it: the name can go
+    if group.rank == 0 and os.path.exists(path):
+        os.unlink(path)
+    return desc, cf, t_build

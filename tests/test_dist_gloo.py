@@ -47,6 +47,51 @@ def test_two_rank_timing_and_sharding():
     assert sorted(m0 + m1) == list(range(7)) and abs(len(m0) - len(m1)) <= 1
 
 
+def _share_worker(rank, world, port, path, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      OMP_NUM_THREADS="1")
+    import numpy as np
+    import plonky2_lib_amd.synth as synth
+    from oracle import oracle
+    g = gdist.init_from_env(use_cuda=False)
+    built = []
+
+    def build():
+        built.append(rank)
+        return synth.arith_circuit(6, synth.Config.standard_recursion_config(), seed=3)
+    desc, cf, t_build = gdist.shared_circuit(g, build, path, seed=77)
+    oc = oracle.OracleCircuit(desc)                               # CPU checker: the rank's own witness must be a valid witness
+    rc, proof = oc.prove(wires=np.ascontiguousarray(desc.wires))
+    ok = rc == 0 and oc.verify(proof) == 0
+    out.put((rank, built, bool(ok), np.asarray(desc.wires).tobytes(), np.asarray(desc.sigmas).tobytes(), proof.tobytes(), os.path.exists(path)))
+    if cf is not None:
+        desc.wires = None
+        cf.close()
+    g.close()
+
+
+def test_eight_ranks_share_one_circuit_file(tmp_path):
+    """bench.py on a multi-GPU node: rank 0 builds the circuit and writes it once as a hand-off file, ranks 1..7 map it (no second
+    build) and put rank-specific values into the unconstrained padding rows: eight different, valid witnesses of one circuit; the
+    file's name is gone once everyone has mapped it."""
+    world, port = 8, _free_port()
+    path = str(tmp_path / "shared.glpc")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_share_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[0]] + [[]] * 7                 # only rank 0 ran build()
+    assert all(r[2] for r in res)                                  # every rank's witness proves and verifies (oracle)
+    assert len({r[3] for r in res}) == 8 and len({r[5] for r in res}) == 8      # eight different witnesses, eight different proofs
+    assert len({r[4] for r in res}) == 1                           # one circuit
+    assert not any(r[6] for r in res) and not os.path.exists(path)
+
+
 def test_single_rank_needs_no_process_group():
     g = gdist.Group()
     assert gdist.timed_steps(g, lambda: None, 2, 1) >= 0.0

@@ -29,6 +29,16 @@ def test_two_ranks_started_by_bench_itself():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None
 
 
+def test_four_ranks_share_the_circuit_file():
+    """The real-circuit bench on several ranks (here four gloo ranks on the one GPU of the box; the box allows six GPU processes, the
+    test runner is one): rank 0 builds the 2^17-row circuit and writes it as a hand-off file, ranks 1..3 map it -- one Python build
+    instead of four -- and every rank verifies its own, different proof."""
+    d = _run(["--gpus", "4", "--force-device", "0", "--dist-backend", "gloo", "--log-n", "17", "--steps", "1", "--warmup", "1",
+              "--no-variants", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 4 and d["verified"] is True and d["signatures_per_proof"] == 1
+    assert "mapped it" in d["config"]["circuit_hand_off"]
+
+
 def test_single_rank_line_has_roofline_verified_and_variants():
     d = _run(["--log-n", "13", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert d["n_gpus"] == 1 and d["verified"] is True

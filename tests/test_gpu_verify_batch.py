@@ -76,7 +76,7 @@ def _tampered_batch(proof, desc, rng):
 def test_verdicts_and_reasons_equal_the_host_verifier(ctx, oracle, which):
     desc = {"zkdsa": lambda: synth.zkdsa_circuit(3), "ecdsa": lambda: synth.ecdsa_shape_circuit(7, seed=8),
             "smt": lambda: synth.smt_shape_circuit(10, seed=9),                      # two FRI reductions
-            "arith_rec": lambda: synth.arith_circuit(12, synth.Config.standard_recursion_config(), seed=2, public_inputs=(3, 4))}[which]()
+            "arith_rec": lambda: synth.arith_circuit(12, synth.Config.standard_recursion_config(), seed=2)}[which]()
     gc = glp.Circuit(ctx, desc)
     oc = oracle.OracleCircuit(desc)
     proof = gc.prove()

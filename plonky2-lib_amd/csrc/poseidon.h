@@ -363,9 +363,20 @@ __device__ __forceinline__ u64 permute_coop(u64 x, int l /* lane in group, 0..15
     }
     return canon(x);
 }
+// 64-bit wavefront shuffles (two ds_bpermute each) for the cooperative forms
+__device__ __forceinline__ u64 shfl64(u64 v, int src) {
+    const u32 lo = (u32)__shfl((int)(u32)v, src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
+    const u32 lo = (u32)__shfl_xor((int)(u32)v, m, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
+}
 #else
 inline void permute(u64 s[12]) { permute_ref(s); }
 inline u64 permute_coop(u64 x, int, int) { return x; }   // device-only; declared for the host parsing pass
+GLF_HD u64 shfl64(u64 v, int) { return v; }
+GLF_HD u64 shfl_xor64(u64 v, int) { return v; }
 #endif
 
 // hashing.rs `compress` (= Hasher::two_to_one): perm(l || r || 0000)[0..4]

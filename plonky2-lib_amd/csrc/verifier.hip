@@ -523,14 +523,8 @@ struct VQArgs {
     u32 oracle_cols[4], ab[16], step_depth[16];
     u64 wN, gA[16];         // root_of_unity(lgN), root_of_unity(ab[r])
 };
-__device__ __forceinline__ u64 shfl64(u64 v, int src) {
-    const u32 lo = (u32)__shfl((int)(u32)v, src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
-    return ((u64)hi << 32) | lo;
-}
-__device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
-    const u32 lo = (u32)__shfl_xor((int)(u32)v, m, 64), hi = (u32)__shfl_xor((int)(u32)(v >> 32), m, 64);
-    return ((u64)hi << 32) | lo;
-}
+using pos::shfl64;
+using pos::shfl_xor64;
 __device__ __forceinline__ ext2 group_sum(ext2 v) {         // sum over the 16 lanes of a group, result on every lane
 #pragma unroll
     for (int m = 8; m >= 1; m >>= 1) v = e_add(v, e_make(shfl_xor64(v.a, m), shfl_xor64(v.b, m)));

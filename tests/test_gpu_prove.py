@@ -321,7 +321,8 @@ def test_proof_bytes_equal_the_oracle_serializer(ctx, oracle, which):
     that follows the Rust writer's call tree instead of the product's flat piece list -- byte for byte, on circuits with
     different column counts, FRI arities and public-input counts.  Both are RECALLED from plonky2 0.1.4 (the reference holds no
     proof bytes): agreement is self-consistency, parity with the fork stays unpinned."""
-    desc = {"arith_rec": lambda: synth.arith_circuit(9, synth.Config.standard_recursion_config(), seed=21, public_inputs=(5, 6, 7)),
+    pi = np.array([5, 6, 7], np.uint64)
+    desc = {"arith_rec": lambda: synth.arith_circuit(9, synth.Config.standard_recursion_config(), seed=21, public_inputs=pi, pi_hash=oracle.hash_no_pad(pi)),
             "ecdsa": lambda: synth.ecdsa_shape_circuit(7, seed=4), "zkdsa": lambda: synth.zkdsa_circuit(3),
             "poseidon_chain": lambda: synth.poseidon_chain_circuit(5)}[which]()
     gc = glp.Circuit(ctx, desc)

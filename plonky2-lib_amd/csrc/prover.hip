@@ -2307,3 +2307,4 @@ int glp_prove_staged(glp_ctx *c, const glp_circuit *cc, glp_witness *w, const ui
 
 #include <stdlib.h>
 #include "prover_batch.inc"
+#include "prover_batch_dev.inc"

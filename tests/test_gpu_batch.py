@@ -112,3 +112,33 @@ def test_batch_argument_errors(ctx):
         g3.prove_batch(c3.wires[None])
     assert "num_challenges" in str(e.value)
     gc.free(); g3.free()
+
+
+def test_host_and_device_transcripts_agree(ctx, oracle):
+    """glp_prove_batch keeps the K Fiat-Shamir transcripts on the GPU (one 16-lane group per proof and transcript step); with
+    GLP_BATCH_HOST_TRANSCRIPT=1 they run on host threads with a round trip per step (the round-2 path, still what
+    KeccakGoldilocksConfig takes).  Same words either way, with public inputs (zkdsa: 12) and without, one and two FRI reductions."""
+    import os
+    K = 9
+    descs, wires, pis = _zkdsa_batch(K)
+    gc = glp.Circuit(ctx, descs[0])
+    dev = gc.prove_batch(wires, pis)
+    os.environ["GLP_BATCH_HOST_TRANSCRIPT"] = "1"
+    try:
+        host = gc.prove_batch(wires, pis)
+    finally:
+        del os.environ["GLP_BATCH_HOST_TRANSCRIPT"]
+    assert (dev == host).all(), "first mismatch at proof %d word %d" % tuple(int(x) for x in np.argwhere(dev != host)[0])
+    assert gc.verify_batch(dev).all()
+    gc.free()
+    desc = synth.smt_shape_circuit(10, seed=3)                       # no public inputs, two reductions
+    gc = glp.Circuit(ctx, desc)
+    w = np.stack([desc.wires, desc.wires])
+    dev = gc.prove_batch(w)
+    os.environ["GLP_BATCH_HOST_TRANSCRIPT"] = "1"
+    try:
+        host = gc.prove_batch(w)
+    finally:
+        del os.environ["GLP_BATCH_HOST_TRANSCRIPT"]
+    assert (dev == host).all() and (dev[0] == gc.prove()).all()
+    gc.free()

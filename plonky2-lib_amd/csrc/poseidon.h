@@ -70,6 +70,10 @@ GLF_HD void permute_ref(u64 s[12]) {
     }
 }
 
+GLF_HD u32 mds_entry(int r, int i) {     // M[r][i] of the circulant-plus-diagonal MDS matrix
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    return C[(i - r + 12) % 12] + (r == 0 && i == 0 ? 8u : 0u);
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 // ---- gfx950 schedule ---------------------------------------------------------------------------
 // Same permutation, restructured for the VALU (the kernel is integer-issue bound, not HBM bound):
@@ -329,6 +333,45 @@ __device__ __forceinline__ void permute(u64 s[12]) {    // canonical in, canonic
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = canon(s[i]);
 }
+// ---- proof-of-work form -------------------------------------------------------------------------------
+// The grinding loop permutes states that differ in ONE input element (the candidate) and looks at ONE output element.  Round 0
+// therefore collapses to one S-box and twelve multiply-adds per candidate: with c_i = sbox(x_i + rc0_i) for the eleven fixed
+// inputs, the state entering round 1's S-boxes is  K_r + M[r][pos] sbox(cand + rc0_pos),  K_r = rc1_r + sum_{i != pos} M[r][i] c_i
+// (pow_round0_consts, once per proof); and the last linear layer is needed for row 7 only.  ~10 % fewer issue slots per candidate.
+// st: the sponge state with the pending inputs written over it (canonical), pos: the slot the candidate goes to; out[r] = K_r (canonical)
+__device__ __forceinline__ void pow_round0_consts(const u64 st[12], u32 pos, u64 out[12]) {
+    u64 c[12];
+    for (int i = 0; i < 12; i++) c[i] = (u32)i == pos ? 0 : canon(sbox7_nc(add(st[i], RC[i])));
+    for (int r = 0; r < 12; r++) {
+        u64 acc = RC[12 + r];
+        for (int i = 0; i < 12; i++) if ((u32)i != pos) acc = add(acc, mul(c[i], (u64)mds_entry(r, i)));
+        out[r] = acc;
+    }
+}
+// s = the state entering the S-box layer of round 1 (any u64 congruent to it); returns output element 7, canonical
+__device__ __forceinline__ u64 permute_tail7(u64 s[12]) {
+#pragma nounroll
+    for (int half = 0; half < 2; half++) {
+#pragma nounroll
+        for (int r = half == 0 ? 1 : 0; r < 4; r++) {
+            sbox_layer_nc(s);
+            if (r == 3) break;                              // half 0: round 3's linear layer is part of the merged block; half 1: row 7 only, below
+            mds_add_nc(s, RCN.k[4 * half + r]);
+        }
+        if (half == 0) {
+            partial_block_nc<3, true>(s, PBM[0]);
+#pragma nounroll
+            for (int b = 0; b < 4; b++) partial_block_nc<4, false>(s, PB4[b]);
+            partial_block_nc<3, false>(s, PB3[0]);
+        }
+    }
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { al += (u64)(u32)s[(i + 7) % 12] * C[i]; ah += (u64)(u32)(s[(i + 7) % 12] >> 32) * C[i]; }
+    ah += al >> 32;
+    return canon(fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32)));
+}
 // ---- one permutation on 12 lanes --------------------------------------------------------------------
 // Latency form for the small levels near the top of a Merkle tree and the small FRI layers, where there are far
 // fewer hashes than lanes: lane l (0..11 of a 16-lane group) owns state element l, S-boxes run 12-wide, and the
@@ -375,6 +418,10 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
 #else
 inline void permute(u64 s[12]) { permute_ref(s); }
 inline u64 permute_coop(u64 x, int, int) { return x; }   // device-only; declared for the host parsing pass
+// device-only below; declared for the host parsing pass
+GLF_HD u64 sbox7_nc(u64 x) { return x; }
+GLF_HD void pow_round0_consts(const u64 *, u32, u64 *) {}
+GLF_HD u64 permute_tail7(u64 *) { return 0; }
 GLF_HD u64 shfl64(u64 v, int) { return v; }
 GLF_HD u64 shfl_xor64(u64 v, int) { return v; }
 #endif

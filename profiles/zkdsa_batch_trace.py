@@ -9,3 +9,6 @@ w = np.stack([d.wires for d in descs]); pis = np.stack([d.public_inputs for d in
 gc.prove_batch(w, pis)
 os.environ["GLP_BATCH_TRACE"] = "1"
 t=time.perf_counter(); gc.prove_batch(w, pis); print("total ms", (time.perf_counter()-t)*1e3)
+p = gc.prove_batch(w, pis)
+pw = p[:, gc.proof_words - len(descs[0].public_inputs) - 1].astype(np.float64)
+print("proof-of-work candidates below the witnesses: sum(w + 1) = %.0f (expected K 2^16 = %.0f), max %.0f" % ((pw + 1).sum(), K * 65536.0, pw.max()))

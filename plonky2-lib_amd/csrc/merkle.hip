@@ -18,7 +18,7 @@ namespace glp {
 using namespace glf;
 
 constexpr size_t MERKLE_COOP_MAX_PARENTS = 8192;   // at or below this many hashes per launch: 12 lanes per hash
-constexpr size_t MERKLE_COOP_MAX_LEAVES = 8192;
+constexpr size_t MERKLE_COOP_MAX_LEAVES = 32768;   // below this the one-state-per-lane kernel leaves most CUs empty (it needs ~2.6e5 leaves to fill the chip; the 12-lane form costs ~5x the lane-cycles per hash)
 
 size_t merkle_num_digests(size_t nleaves, int cap_height) {
     size_t t = 0, w = nleaves, cap = (size_t)1 << cap_height;

@@ -1,5 +1,5 @@
 import numpy as np, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plonky2_lib_amd as glp, plonky2_lib_amd.synth as synth
 K = 256
 rng = np.random.default_rng(1)

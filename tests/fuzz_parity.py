@@ -2,7 +2,9 @@
 """Randomised parity campaign (a tool, not collected by pytest): random CircuitConfig / FriConfig fields, trace sizes,
 gate mixes and public inputs; for each case the HIP library's proof must equal the CPU oracle's word for word, both
 verifiers must accept it and reject a tampered copy; (round 2) the row-local witness generators on the GPU must rebuild a scrambled
-witness exactly as the oracle's do, and with two challenges a two-proof glp_prove_batch must return the single proofs.  Usage: python tests/fuzz_parity.py [cases] [seed]   (FUZZ_MIN_LG / FUZZ_MAX_LG bound the trace length, default 5..11)"""
+witness exactly as the oracle's do, and with two challenges a two-proof glp_prove_batch (round 3: its transcripts on the device) must return the
+single proofs; (round 3) glp_verify_batch must give glp_verify's verdicts and reasons, glp_proof_to_bytes the oracle serializer's bytes, and a witness staged
+from page-locked memory with its advice columns derived on the GPU the proof of the oracle-derived witness.  Usage: python tests/fuzz_parity.py [cases] [seed]   (FUZZ_MIN_LG / FUZZ_MAX_LG bound the trace length, default 5..11)"""
 import os
 import sys
 import time
@@ -119,6 +121,22 @@ def main():
         if desc.num_challenges == 2:             # the batch path: two proofs (the witness and its regenerated twin) in lock step
             both = gc.prove_batch(np.stack([desc.wires, back]), np.stack([desc.public_inputs, desc.public_inputs]) if len(desc.public_inputs) else None)
             ok = ok and (both[0] == got).all() and (both[1] == gc.prove(wires=back)).all()
+        # round 3: the batch verifier (query rounds on the GPU) against the host verifier, verdict and reason; the oracle's own proof serializer;
+        # a witness staged from page-locked host memory, routed columns only (advice columns derived on the GPU)
+        vok, why = gc.verify_batch(np.stack([got, bad, got]), reasons=True)
+        host_ok = gc.verify(bad)
+        ok = ok and list(vok) == [True, False, True] and not host_ok and why[1] == glp.load_library().glp_last_error().decode()
+        ok = ok and gc.proof_to_bytes(got) == oc.proof_to_bytes(got)
+        nr_ = desc.num_routed_wires
+        pinned = ctx.host_alloc((nr_, 1 << desc.degree_bits))
+        pinned[:] = desc.wires[:nr_]
+        st = gc.stage_witness(pinned, routed_only=True)
+        staged = gc.prove_staged(st)
+        st.free()
+        ctx.host_free(pinned)
+        w0 = desc.wires.copy()
+        w0[nr_:] = 0
+        ok = ok and (staged == gc.prove(wires=oc.witness_fill(w0, only_advice=True))).all()
         print("case %3d %s  %s  (%.0f s)" % (i, "ok  " if ok else "FAIL", info, time.time() - t0), flush=True)
         if not ok:
             if rc == 0 and not (got == ref).all():

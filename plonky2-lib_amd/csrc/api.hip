@@ -113,10 +113,6 @@ int glp_ctx_create(int device_id, glp_ctx **out) {
             return set_error(GLP_ERR_HIP, "hipStreamCreateWithFlags (copy stream): %s", hipGetErrorString(e2));
         }
     }
-    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) c->aux_stream = nullptr;
-    for (int i = 0; i < GLP_AUX_EVENTS && c->aux_stream; i++)
-        if (hipEventCreateWithFlags(&c->aux_events[i], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->aux_stream); c->aux_stream = nullptr; }
-    if (const char *e4 = getenv("GLP_LDE_OVERLAP")) { const int v = atoi(e4); if (v >= 0 && v <= 16) c->lde_overlap = v; }
     *out = c.release();
     return GLP_OK;
 }
@@ -131,8 +127,6 @@ void glp_ctx_destroy(glp_ctx *c) {
     c->trim();
     for (auto &kv : c->live) (void)hipFree(kv.first);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    for (int i = 0; i < GLP_AUX_EVENTS; i++) if (c->aux_events[i]) (void)hipEventDestroy(c->aux_events[i]);
-    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }

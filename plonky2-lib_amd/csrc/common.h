@@ -57,14 +57,10 @@ struct Stage {
 
 }  // namespace glp
 
-constexpr int GLP_AUX_EVENTS = 32;
 struct glp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;   // host->device witness chunks, overlapped with the transforms of earlier chunks
-    hipStream_t aux_stream = nullptr;    // second compute stream: the strided NTT pass of one column chunk beside the contiguous pass of the next
-    hipEvent_t aux_events[GLP_AUX_EVENTS] = {};
-    int lde_overlap = 0;                 // column chunks of the two-stream LDE (GLP_LDE_OVERLAP; 0 / 1 = one stream)
     int num_cus = 256;
     // size-keyed free lists: commit buffers are GB-sized and recur with identical sizes every proof
     std::multimap<size_t, void *> pool;

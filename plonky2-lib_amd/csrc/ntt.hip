@@ -993,38 +993,6 @@ static int lde_coeffs_chunk(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32
         GLP_HIP(hipGetLastError());
         return GLP_OK;
     }
-    // Column chunks on two streams: the contiguous pass (VALU-bound) of chunk i + 1 runs beside the strided pass (HBM-bound) of
-    // chunk i.  GLP_LDE_OVERLAP = number of chunks (0 / 1: one stream, the default until measured).
-    if (c->lde_overlap > 1 && np->lgB == 12 && np->lgA >= 8 && np->lgA <= 10 && ncols >= 2 * (u32)c->lde_overlap && c->aux_stream) {
-        const u32 nchunk = (u32)c->lde_overlap, per = (ncols + nchunk - 1) / nchunk;
-        const size_t n = (size_t)1 << lg;
-        u32 ei = 0;
-        for (u32 c0 = 0; c0 < ncols; c0 += per) {
-            const u32 cn = std::min(per, ncols - c0);
-            const u64 *src = dev_coeffs + (size_t)c0 * n;
-            u64 *dst = dev_lde + (size_t)c0 * R * n;
-            hipLaunchKernelGGL(k_lde_contig16, dim3(1u << np->lgA, cn), dim3(TPB), 0, c->stream, src, dst, np->tw4096, lp->pre, lp->s_r, np->w_n, lg, np->lgA, R, 0);
-            GLP_HIP(hipGetLastError());
-            hipEvent_t ev = c->aux_events[ei++ % GLP_AUX_EVENTS];
-            GLP_HIP(hipEventRecord(ev, c->stream));
-            GLP_HIP(hipStreamWaitEvent(c->aux_stream, ev, 0));
-            hipStream_t keep = c->stream;
-            c->stream = c->aux_stream;                       // the strided launchers take the context's stream
-            int rc = GLP_OK;
-            if (np->lgA == 8) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_strided16<false>), dim3((1u << np->lgB) / NTT_STRIDED_W, cn * R), dim3(TPB), 0, c->stream, dst, dst, np->tw4096, lg, np->lgB);
-                if (hipGetLastError() != hipSuccess) rc = set_error(GLP_ERR_HIP, "k_strided16 launch failed");
-            } else {
-                rc = launch_strided32<false>(c, dst, dst, np->tw4096, lg, np->lgA, np->lgB, cn * R);
-            }
-            c->stream = keep;
-            GLP_TRY(rc);
-        }
-        hipEvent_t done = c->aux_events[ei % GLP_AUX_EVENTS];
-        GLP_HIP(hipEventRecord(done, c->aux_stream));
-        GLP_HIP(hipStreamWaitEvent(c->stream, done, 0));
-        return GLP_OK;
-    }
     dim3 g1(1u << np->lgA, ncols);
     if (np->lgB == 12)
         hipLaunchKernelGGL(k_lde_contig16, g1, dim3(TPB), 0, c->stream, dev_coeffs, dev_lde, np->tw4096, lp->pre, lp->s_r,

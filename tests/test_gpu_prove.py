@@ -280,8 +280,9 @@ def test_stand_in_2_20_verifies(ctx, oracle):
 
 
 def test_prove_2_21_rows_verifies(ctx, oracle):
-    """Past the two-pass NTT limit: 2^21 rows x 135 wires (three-pass transforms, 5 FRI reductions); the proof
-    must satisfy the oracle verifier (constants/sigmas cap taken from the circuit object)."""
+    """2^21 rows x 135 wires, 5 FRI reductions: the transforms are two passes with the 512-row LDS tiles of k_strided32 (three passes
+    until round 3; the real 20-signature circuit of this size: tests/test_gpu_ecdsa_circuit.py::test_perf_rs_twenty_signatures_2_21); the
+    proof must satisfy the oracle verifier (constants/sigmas cap taken from the circuit object)."""
     desc = synth.arith_circuit(21, synth.Config.standard_recursion_config(), seed=21)
     gc = glp.Circuit(ctx, desc)
     proof = gc.prove()

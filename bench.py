@@ -563,8 +563,15 @@ def main():
                 raise SystemExit("bench.py: %d signatures gave 2^%d rows, expected 2^%d" % (nsig, d.degree_bits, lg))
             return d
         if share:
+            # the file is (num_constants + 80 + 136) columns of 2^lg words (1.9 GB at 2^20): /dev/shm if it has the room (a container's
+            # default is 64 MB), else the temporary directory, else every rank builds its own circuit after all
+            import shutil
             import tempfile
-            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            need = int(1.25 * (4 + 80 + 136) * 8 * (1 << lg)) + (1 << 20)
+            base = next((d for d in ("/dev/shm", tempfile.gettempdir())
+                         if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need), None)
+            share = base is not None
+        if share:
             shared_file = os.path.join(base, "glp_bench_%s_%d.glpc" % (os.environ.get("MASTER_PORT", "0"), lg))
             desc, cf, t_build = gdist.shared_circuit(grp, build_circuit, shared_file, SEED)
         else:

@@ -251,7 +251,8 @@ GLP_API int glp_prove_device(glp_ctx *ctx, const glp_circuit *circuit, const uin
  *     glp_prove_staged(ctx, circuit, w_cur, public_inputs, proof_out);    the compute stream waits for w_cur's copy, then proves
  *     glp_witness_free(w_cur);
  * For the copy to overlap anything the host buffer must be page-locked: glp_host_alloc hands out such memory (have witness
- * generation write into it); pageable memory works and is staged by the HIP runtime, synchronously.
+ * generation write into it); pageable memory works and is staged by the HIP runtime, synchronously.  Either way host_wires must stay
+ * valid and unchanged until glp_prove_staged has returned for that witness (or glp_witness_free has).
  * GLP_WITNESS_ROUTED_ONLY: host_wires holds only the routed columns [num_routed_wires][n] (= the first columns of the full
  * [num_wires][n] layout, so the full array may be passed as well); the advice columns are zero-filled on the device and derived
  * there by glp_witness_fill(only_advice) before the proof starts -- for the secp256k1 trace 56 of 136 columns (41 %) never cross

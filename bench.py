@@ -272,6 +272,13 @@ def pipelined_variant(glp, ctx, circuit, desc, device, resident_proof, np, steps
     nr, n = int(desc.num_routed_wires), 1 << int(desc.degree_bits)
 
     def pipeline(c_ctx, c_circuit, count, sink):
+        try:
+            pipeline_body(c_ctx, c_circuit, count, sink)
+        except BaseException as e:                          # a failing pipeline must not leave the main thread waiting
+            sink["error"] = e
+            sink["filled"].set()
+
+    def pipeline_body(c_ctx, c_circuit, count, sink):
         pinned = c_ctx.host_alloc((nr, n))
         pinned[:] = desc.wires[:nr]
         # steady state before the clock starts: one proof done, the next witness already on its way
@@ -302,6 +309,9 @@ def pipelined_variant(glp, ctx, circuit, desc, device, resident_proof, np, steps
         for t in th:
             t.join()
         dt = time.perf_counter() - t0
+        for sk in sinks:
+            if "error" in sk:
+                raise SystemExit("bench.py: pipelined_from_host failed: %r" % (sk["error"],))
         for (pc, _), sk in zip(pipes, sinks):
             pc.host_free(sk["pinned"])
         return dt, sinks

@@ -10,6 +10,7 @@
 // shifts, the digest and the constants/sigmas cap).  It shares no code with the CPU checker the tests use: the two
 // verifiers and the two provers are cross-checked against each other in tests/test_gpu_prove.py.
 #include <string>
+#include <thread>
 #include "merkle.h"
 #include "prover_types.h"
 
@@ -683,6 +684,19 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     std::vector<int> rc(K, GLP_OK);
     std::vector<std::string> why(K);
     std::vector<u64> hv((size_t)K * vstride, 0);
+    // the proofs go up (pageable host memory: the copy blocks its caller) on a thread of their own while the host half runs
+    struct Scratch { glp_ctx *c; std::vector<void *> p; ~Scratch() { (void)hipStreamSynchronize(c->stream); for (void *q : p) c->release(q); } } sc{c, {}};
+    auto get = [&](void **p, size_t bytes) -> int { int r = c->alloc(p, bytes); if (r == GLP_OK) sc.p.push_back(*p); return r; };
+    u64 *dev_proofs = nullptr, *dev_vc = nullptr;
+    u32 *dev_status = nullptr;
+    GLP_TRY(get((void **)&dev_proofs, (size_t)K * L.total * 8));
+    GLP_TRY(get((void **)&dev_vc, hv.size() * 8));
+    GLP_TRY(get((void **)&dev_status, (size_t)K * nq * 4));
+    hipError_t up_err = hipSuccess;
+    std::thread uploader([&] {
+        up_err = hipSetDevice(c->device);
+        if (up_err == hipSuccess) up_err = hipMemcpyAsync(dev_proofs, proofs, (size_t)K * L.total * 8, hipMemcpyHostToDevice, c->stream);
+    });
     // host half, one proof per task on the context's pool: canonical form, transcript, proof of work, vanishing polynomial at zeta
     ctx_host_pool(c).run(K, [&](size_t k) {
         rc[k] = verify_front(cc, proofs + k * L.total, vcs[k]);
@@ -696,14 +710,8 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     });
     // device half: every query round of every proof in one launch.  Proofs the host half already rejected still ride along
     // (their slots hold zero challenges and every index is in range); their device status is ignored.
-    struct Scratch { glp_ctx *c; std::vector<void *> p; ~Scratch() { (void)hipStreamSynchronize(c->stream); for (void *q : p) c->release(q); } } sc{c, {}};
-    auto get = [&](void **p, size_t bytes) -> int { int r = c->alloc(p, bytes); if (r == GLP_OK) sc.p.push_back(*p); return r; };
-    u64 *dev_proofs = nullptr, *dev_vc = nullptr;
-    u32 *dev_status = nullptr;
-    GLP_TRY(get((void **)&dev_proofs, (size_t)K * L.total * 8));
-    GLP_TRY(get((void **)&dev_vc, hv.size() * 8));
-    GLP_TRY(get((void **)&dev_status, (size_t)K * nq * 4));
-    GLP_HIP(hipMemcpyAsync(dev_proofs, proofs, (size_t)K * L.total * 8, hipMemcpyHostToDevice, c->stream));
+    uploader.join();
+    if (up_err != hipSuccess) return set_error(GLP_ERR_HIP, "upload of the proofs: %s", hipGetErrorString(up_err));
     GLP_HIP(hipMemcpyAsync(dev_vc, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
     VQArgs a;
     memset(&a, 0, sizeof(a));

@@ -38,14 +38,18 @@ E range_product(E v, u32 bound) {
     return p;
 }
 E sbox7(E x) { const E x2 = x * x, x4 = x2 * x2, x3 = x * x2; return x3 * x4; }
-void mds(E s[12]) {
+void mds(E s[12]) {     // circulant + diagonal, entries < 64: both coordinates accumulate unreduced in 128 bits, one reduction per row and coordinate
     static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     E o[12];
     for (int r = 0; r < 12; r++) {
-        E acc = ZERO;
-        for (int i = 0; i < 12; i++) acc = acc + s[(i + r) % 12] * C[i];
-        if (r == 0) acc = acc + s[0] * (u64)8;
-        o[r] = acc;
+        unsigned __int128 a = 0, b = 0;
+        for (int i = 0; i < 12; i++) {
+            const ext2 &x = s[(i + r) % 12].v;
+            a += (unsigned __int128)x.a * C[i];
+            b += (unsigned __int128)x.b * C[i];
+        }
+        if (r == 0) { a += (unsigned __int128)s[0].v.a * 8; b += (unsigned __int128)s[0].v.b * 8; }
+        o[r] = E(e_make(reduce128((u64)a, (u64)(a >> 64)), reduce128((u64)b, (u64)(b >> 64))));
     }
     for (int r = 0; r < 12; r++) s[r] = o[r];
 }

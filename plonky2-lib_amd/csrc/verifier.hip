@@ -9,6 +9,7 @@
 // host, like the transcript, and touches no device memory (the circuit handle supplies the gate table, the coset
 // shifts, the digest and the constants/sigmas cap).  It shares no code with the CPU checker the tests use: the two
 // verifiers and the two provers are cross-checked against each other in tests/test_gpu_prove.py.
+#include <chrono>
 #include <string>
 #include <thread>
 #include "merkle.h"
@@ -696,6 +697,9 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     GLP_TRY(get((void **)&dev_proofs, (size_t)K * L.total * 8));
     GLP_TRY(get((void **)&dev_vc, hv.size() * 8));
     GLP_TRY(get((void **)&dev_status, (size_t)K * nq * 4));
+    const bool trace = getenv("GLP_BATCH_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     hipError_t up_err = hipSuccess;
     std::thread uploader([&] {
         up_err = hipSetDevice(c->device);
@@ -714,7 +718,9 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     });
     // device half: every query round of every proof in one launch.  Proofs the host half already rejected still ride along
     // (their slots hold zero challenges and every index is in range); their device status is ignored.
+    const double t_front = since();
     uploader.join();
+    const double t_up = since();
     if (up_err != hipSuccess) return set_error(GLP_ERR_HIP, "upload of the proofs: %s", hipGetErrorString(up_err));
     GLP_HIP(hipMemcpyAsync(dev_vc, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
     VQArgs a;
@@ -738,6 +744,7 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     std::vector<u32> hs((size_t)K * nq);
     GLP_HIP(hipMemcpyAsync(hs.data(), dev_status, hs.size() * 4, hipMemcpyDeviceToHost, c->stream));
     GLP_HIP(hipStreamSynchronize(c->stream));
+    if (trace) fprintf(stderr, "[glp_verify_batch K=%u] host half %.3f ms | upload done at %.3f | query rounds done at %.3f ms\n", K, t_front, t_up, since());
     for (u32 k = 0; k < K; k++) {
         if (rc[k] == GLP_OK)
             for (u32 q = 0; q < nq && rc[k] == GLP_OK; q++)

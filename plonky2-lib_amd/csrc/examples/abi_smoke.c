@@ -5,6 +5,7 @@
  *   gcc -std=c99 -Wall -Werror -I../../../include abi_smoke.c -L../.. -lglprover -Wl,-rpath,'$ORIGIN/../..' -o abi_smoke */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "glp.h"
 
 /* argv[1] (optional): a circuit hand-off file (glp_circuit_file_*, host-only code: this part runs without a GPU).  With a GPU the
@@ -49,6 +50,35 @@ int main(int argc, char **argv) {
         if (glp_prove(ctx, circuit, glp_circuit_file_wires(cf), glp_circuit_file_public_inputs(cf), proof) != GLP_OK ||
             glp_verify_n(circuit, proof, words) != GLP_OK) { fprintf(stderr, "%s\n", glp_last_error()); return 1; }
         printf("proved and verified the circuit of %s (%zu proof words)\n", argv[1], words);
+        /* the pipelined hand-over: the witness in page-locked memory, staged on the copy stream, proved from the staged copy; then both
+         * proofs and a damaged one through the batch verifier (query rounds on the GPU) */
+        const glp_circuit_desc *d = glp_circuit_file_desc(cf);
+        const size_t wbytes = sizeof(uint64_t) * d->num_wires << d->degree_bits;
+        void *pinned = NULL;
+        glp_witness *staged = NULL;
+        uint64_t *three = (uint64_t *)malloc(sizeof(uint64_t) * words * 3);
+        if (glp_host_alloc(ctx, wbytes, &pinned) != GLP_OK) { fprintf(stderr, "%s\n", glp_last_error()); return 1; }
+        memcpy(pinned, glp_circuit_file_wires(cf), wbytes);
+        if (glp_witness_stage(ctx, circuit, (const uint64_t *)pinned, 0, &staged) != GLP_OK ||
+            glp_prove_staged(ctx, circuit, staged, glp_circuit_file_public_inputs(cf), three + words) != GLP_OK) {
+            fprintf(stderr, "%s\n", glp_last_error());
+            return 1;
+        }
+        glp_witness_free(staged);
+        glp_host_free(ctx, pinned);
+        if (memcmp(proof, three + words, sizeof(uint64_t) * words) != 0) { fprintf(stderr, "the staged proof differs from glp_prove's\n"); return 1; }
+        memcpy(three, proof, sizeof(uint64_t) * words);
+        memcpy(three + 2 * words, proof, sizeof(uint64_t) * words);
+        three[2 * words + words / 2] ^= 1;
+        int32_t status[3];
+        char reasons[3 * GLP_REASON_LEN];
+        if (glp_verify_batch(ctx, circuit, 3, three, status, reasons) != GLP_OK) { fprintf(stderr, "%s\n", glp_last_error()); return 1; }
+        if (status[0] != GLP_OK || status[1] != GLP_OK || status[2] != GLP_ERR_PROVE || reasons[0] || !reasons[2 * GLP_REASON_LEN]) {
+            fprintf(stderr, "glp_verify_batch verdicts %d %d %d\n", status[0], status[1], status[2]);
+            return 1;
+        }
+        printf("staged proof equal; batch verifier: ok, ok, rejected (%s)\n", reasons + 2 * GLP_REASON_LEN);
+        free(three);
         free(proof);
         glp_circuit_free(circuit);
     }

@@ -85,3 +85,4 @@ def test_c99_consumer_proves_the_sample_circuit_file(tmp_path):
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "zkdsa_2_3.glpc")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "circuit file ok: 2^3 rows, 135 wires" in r.stdout and "proved and verified" in r.stdout and "abi_smoke ok" in r.stdout
+    assert "staged proof equal; batch verifier: ok, ok, rejected (" in r.stdout

@@ -54,6 +54,8 @@ GLP_API int glp_device_count(void);
  *   GLP_NTT_2PASS_LG      = 20..22 (default 22): largest log2(n) transformed in two passes; above it a third pass over 2^20-point blocks
  *   GLP_NTT_STRIDED32_LW  = 3 | 4  (default 4):  log2 columns of the 512- / 1024-row strided tile (64- or 128-byte row segments)
  *   GLP_NTT_STRIDED32_TL  = 1..64  (default 8):  tiles one block of that kernel walks, software-pipelined (1 = one tile per block)
+ *   GLP_MERKLE_COOP_MAX   (default 4096), GLP_MERKLE_QUAD_MAX (default 32768): Poseidon leaf hashing spreads one sponge over 12 of 16 lanes up to
+ *                         the first many leaves per launch, over a quad of lanes up to the second, and keeps one sponge per lane above it
  *   GLP_HOST_THREADS      (read on the first glp_prove_batch of a context): host threads for the transcripts of a batch */
 GLP_API int glp_ctx_create(int device_id, glp_ctx **out);
 GLP_API void glp_ctx_destroy(glp_ctx *ctx);

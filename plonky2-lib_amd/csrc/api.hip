@@ -105,6 +105,8 @@ int glp_ctx_create(int device_id, glp_ctx **out) {
     if (const char *e1 = getenv("GLP_NTT_2PASS_LG")) { const int v = atoi(e1); if (v >= NTT_INNER_LG && v <= NTT_2PASS_LG) c->two_pass_lg = v; }
     if (const char *e2 = getenv("GLP_NTT_STRIDED32_TL")) { const int v = atoi(e2); if (v >= 1 && v <= 64) c->strided32_tl = v; }
     if (const char *e3 = getenv("GLP_NTT_STRIDED32_LW")) { const int v = atoi(e3); if (v == 3 || v == 4) c->strided32_lw = v; }
+    if (const char *e4 = getenv("GLP_MERKLE_COOP_MAX")) c->merkle_coop_max = (size_t)strtoull(e4, nullptr, 10);
+    if (const char *e5 = getenv("GLP_MERKLE_QUAD_MAX")) c->merkle_quad_max = (size_t)strtoull(e5, nullptr, 10);
     GLP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         hipError_t e2 = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);

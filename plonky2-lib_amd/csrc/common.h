@@ -72,6 +72,8 @@ struct glp_ctx {
     int two_pass_lg = 22;                // largest log_n transformed in two passes (ntt.h NTT_2PASS_LG; GLP_NTT_2PASS_LG overrides, 20..22)
     int strided32_tl = 8;                // tiles (planes) a k_strided32 block walks, software-pipelined (GLP_NTT_STRIDED32_TL: 1..64; 1 = no pipelining)
     int strided32_lw = 4;                // log2 columns of a k_strided32 tile (GLP_NTT_STRIDED32_LW: 3 = 64-byte row segments, 4 = 128-byte)
+    size_t merkle_coop_max = 4096;       // leaf hash: up to this many leaves per launch one leaf per 16-lane group (GLP_MERKLE_COOP_MAX), ...
+    size_t merkle_quad_max = 32768;      // ... up to this many one leaf per quad of lanes (GLP_MERKLE_QUAD_MAX), above it one leaf per lane (merkle.hip)
     void *host_pool = nullptr;           // HostPool of prover_batch.inc (host threads for the transcripts of a batch), made on first use
     void (*host_pool_free)(void *) = nullptr;
     bool profiling = false;

@@ -18,7 +18,8 @@ namespace glp {
 using namespace glf;
 
 constexpr size_t MERKLE_COOP_MAX_PARENTS = 8192;   // at or below this many hashes per launch: 12 lanes per hash
-constexpr size_t MERKLE_COOP_MAX_LEAVES = 32768;   // below this the one-state-per-lane kernel leaves most CUs empty (it needs ~2.6e5 leaves to fill the chip; the 12-lane form costs ~5x the lane-cycles per hash)
+// Leaf hashing has three forms (crossovers measured by profiles/leaf_form_probe.py, 135 columns: 12-lane 0.27 ms / quad 0.34 / one per lane 0.65 at
+// 2^12 leaves; 0.61 / 0.36 / 0.65 at 2^14; 2.09 / 0.83 / 0.66 at 2^16): the thresholds are glp_ctx::merkle_coop_max / merkle_quad_max.
 
 size_t merkle_num_digests(size_t nleaves, int cap_height) {
     size_t t = 0, w = nleaves, cap = (size_t)1 << cap_height;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256, 4) void k_leaf_hash_lde(const u64 *__restrict_
     store_digest(digests + 4 * leaf, s);
 }
 
-// Latency form of the leaf hash for small trees (N <= MERKLE_COOP_MAX_LEAVES): one leaf per 16-lane group, the
+// Latency form of the leaf hash for small trees (N <= glp_ctx::merkle_coop_max): one leaf per 16-lane group, the
 // sponge state spread over 12 lanes (pos::permute_coop).  17 sequential permutations per leaf take ~0.2 ms here
 // instead of ~0.95 ms with one state per lane.
 __global__ __launch_bounds__(256) void k_leaf_hash_lde_coop(const u64 *__restrict__ lde, u64 *__restrict__ digests,
@@ -97,6 +98,37 @@ __global__ __launch_bounds__(256) void k_leaf_hash_lde_coop(const u64 *__restric
         x = pos::permute_coop(x, l, group_base);
     }
     if (live && l < 4) digests[4 * leaf + l] = x;
+}
+
+// The form between the two (merkle_coop_max < N <= merkle_quad_max): one leaf per quad of lanes, three state elements per
+// lane (pos::permute_quad); 64 leaves per workgroup.  Lane q takes elements 3q..3q+2 of each block of eight columns.
+__global__ __launch_bounds__(256) void k_leaf_hash_lde_quad(const u64 *__restrict__ lde, u64 *__restrict__ digests,
+                                                            u32 ncols, int lg, int rate_bits, size_t lde_stride, size_t dig_stride) {
+    lde += (size_t)blockIdx.y * lde_stride; digests += (size_t)blockIdx.y * dig_stride;
+    const size_t N = (size_t)1 << (lg + rate_bits);
+    const int tid = threadIdx.x, q = tid & 3;
+    const size_t pos = (size_t)blockIdx.x * 64 + (tid >> 2);
+    const bool live = pos < N;
+    const size_t p = live ? pos : 0;
+    const u32 r = (u32)(p >> lg), qq = (u32)(p & (((size_t)1 << lg) - 1));
+    const size_t leaf = ((size_t)bitrev32(r, rate_bits) << lg) | bitrev32(qq, lg);
+    if (ncols <= 4) {
+        if (live) digests[4 * leaf + q] = (u32)q < ncols ? lde[(size_t)q * N + p] : 0;
+        return;
+    }
+    u64 x[3] = {0, 0, 0};
+    for (u32 c = 0; c < ncols; c += 8) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            const u32 e = 3 * q + s;
+            if (e < 8 && c + e < ncols) x[s] = lde[(size_t)(c + e) * N + p];
+        }
+        pos::permute_quad(x, q);
+    }
+    if (live) {
+        if (q == 0) { digests[4 * leaf] = x[0]; digests[4 * leaf + 1] = x[1]; digests[4 * leaf + 2] = x[2]; }
+        if (q == 1) digests[4 * leaf + 3] = x[0];
+    }
 }
 
 // hash_or_noop of row-major leaves [nleaves][leaf_len]
@@ -239,8 +271,11 @@ int merkle_from_lde(glp_ctx *c, const u64 *dev_lde, u32 ncols, int lg, int rate_
         if (hasher == GLP_HASH_KECCAK25)
             hipLaunchKernelGGL(k_leaf_hash_lde_keccak, dim3((unsigned)((N + 255) / 256), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
                                ncols, lg, rate_bits, lde_stride, dig_stride);
-        else if (N * K <= MERKLE_COOP_MAX_LEAVES)
+        else if (N * K <= c->merkle_coop_max)
             hipLaunchKernelGGL(k_leaf_hash_lde_coop, dim3((unsigned)((N + 15) / 16), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
+                               ncols, lg, rate_bits, lde_stride, dig_stride);
+        else if (N * K <= c->merkle_quad_max)
+            hipLaunchKernelGGL(k_leaf_hash_lde_quad, dim3((unsigned)((N + 63) / 64), K), dim3(256), 0, c->stream, dev_lde, dev_digests,
                                ncols, lg, rate_bits, lde_stride, dig_stride);
         else
             hipLaunchKernelGGL(k_leaf_hash_lde, dim3((unsigned)((N + 255) / 256), K), dim3(256), 0, c->stream, dev_lde, dev_digests,

@@ -348,8 +348,11 @@ __device__ __forceinline__ void pow_round0_consts(const u64 st[12], u32 pos, u64
         out[r] = acc;
     }
 }
-// s = the state entering the S-box layer of round 1 (any u64 congruent to it); returns output element 7, canonical
-__device__ __forceinline__ u64 permute_tail7(u64 s[12]) {
+// s = the state entering the S-box layer of round 1 (any u64 congruent to it); returns output element 7, canonical.
+// give_up() is asked at four points on the way (after rounds 3, 14, 25 and 27): true = the caller has no use for the result any more
+// (a smaller witness is known), the function returns ~0 at once.
+template <class GiveUp>
+__device__ __forceinline__ u64 permute_tail7(u64 s[12], GiveUp give_up) {
 #pragma nounroll
     for (int half = 0; half < 2; half++) {
 #pragma nounroll
@@ -357,12 +360,18 @@ __device__ __forceinline__ u64 permute_tail7(u64 s[12]) {
             sbox_layer_nc(s);
             if (r == 3) break;                              // half 0: round 3's linear layer is part of the merged block; half 1: row 7 only, below
             mds_add_nc(s, RCN.k[4 * half + r]);
+            if (half == 1 && r == 1 && give_up()) return ~0ull;
         }
         if (half == 0) {
+            if (give_up()) return ~0ull;
             partial_block_nc<3, true>(s, PBM[0]);
 #pragma nounroll
-            for (int b = 0; b < 4; b++) partial_block_nc<4, false>(s, PB4[b]);
+            for (int b = 0; b < 4; b++) {
+                partial_block_nc<4, false>(s, PB4[b]);
+                if (b == 1 && give_up()) return ~0ull;
+            }
             partial_block_nc<3, false>(s, PB3[0]);
+            if (give_up()) return ~0ull;
         }
     }
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
@@ -372,6 +381,7 @@ __device__ __forceinline__ u64 permute_tail7(u64 s[12]) {
     ah += al >> 32;
     return canon(fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32)));
 }
+__device__ __forceinline__ u64 permute_tail7(u64 s[12]) { return permute_tail7(s, [] { return false; }); }
 // ---- one permutation on 12 lanes --------------------------------------------------------------------
 // Latency form for the small levels near the top of a Merkle tree and the small FRI layers, where there are far
 // fewer hashes than lanes: lane l (0..11 of a 16-lane group) owns state element l, S-boxes run 12-wide, and the
@@ -406,6 +416,54 @@ __device__ __forceinline__ u64 permute_coop(u64 x, int l /* lane in group, 0..15
     }
     return canon(x);
 }
+// ---- one permutation on 4 lanes -----------------------------------------------------------------------
+// Between the two forms above: lane q of a quad (4 adjacent lanes) owns state elements 3q, 3q+1, 3q+2.  The circulant row of
+// element 3q+a reads x[(3q + a + i) % 12] = slot (a + i) % 3 of the lane ((a + i) / 3) places further round the quad: the nine foreign
+// words arrive by DPP quad rotations (v_mov_b32 quad_perm, full rate, no LDS), the coefficients stay compile-time constants.
+// Per lane a full round is 3 S-boxes + 72 multiply-adds, a partial round 1 + 72 -- about 7.6 k instructions per permutation on
+// 4 lanes against 14 k on one and 5.5 k on sixteen: for trees of 2^12..2^16 leaves, where one state per lane leaves most SIMDs
+// empty and the 12-lane form has more lanes than the chip has slots.  x[s]: canonical in, canonical out; whole quads must call it.
+template <int D> __device__ __forceinline__ u32 quad_rot(u32 v) {      // lane q receives v of lane (q + D) % 4 of its quad
+    constexpr int CTRL = (D & 3) | (((D + 1) & 3) << 2) | (((D + 2) & 3) << 4) | (((D + 3) & 3) << 6);
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void permute_quad(u64 x[3], int q /* lane in quad, 0..3 */) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    const u64 *rc = RC + 3 * q;
+    const u32 diag = q == 0 ? 8u : 0u;                          // M[0][0] = C[0] + 8
+#pragma unroll
+    for (int s = 0; s < 3; s++) x[s] = add(x[s], rc[s]);
+#pragma nounroll
+    for (int r = 0; r < 30; r++) {
+        const bool full = r < 4 || r >= 26;
+        const u64 sb = sbox7_nc(x[0]);
+        if (full) { x[0] = sb; x[1] = sbox7_nc(x[1]); x[2] = sbox7_nc(x[2]); }
+        else if (q == 0) x[0] = sb;
+        u32 lo[4][3], hi[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            lo[0][s] = (u32)x[s]; hi[0][s] = (u32)(x[s] >> 32);
+            lo[1][s] = quad_rot<1>(lo[0][s]); hi[1][s] = quad_rot<1>(hi[0][s]);
+            lo[2][s] = quad_rot<2>(lo[0][s]); hi[2][s] = quad_rot<2>(hi[0][s]);
+            lo[3][s] = quad_rot<3>(lo[0][s]); hi[3][s] = quad_rot<3>(hi[0][s]);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const u64 rcn = r < 29 ? rc[12 * (r + 1) + a] : 0;
+            u64 al = (u32)rcn;
+#pragma unroll
+            for (int i = 0; i < 12; i++) al += (u64)lo[((a + i) / 3) & 3][(a + i) % 3] * C[i];
+            if (a == 0) al += (u64)lo[0][0] * diag;
+            u64 ah = (al >> 32) + (rcn >> 32);
+#pragma unroll
+            for (int i = 0; i < 12; i++) ah += (u64)hi[((a + i) / 3) & 3][(a + i) % 3] * C[i];
+            if (a == 0) ah += (u64)hi[0][0] * diag;
+            x[a] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) x[s] = canon(x[s]);
+}
 // 64-bit wavefront shuffles (two ds_bpermute each) for the cooperative forms
 __device__ __forceinline__ u64 shfl64(u64 v, int src) {
     const u32 lo = (u32)__shfl((int)(u32)v, src, 64), hi = (u32)__shfl((int)(u32)(v >> 32), src, 64);
@@ -418,10 +476,12 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
 #else
 inline void permute(u64 s[12]) { permute_ref(s); }
 inline u64 permute_coop(u64 x, int, int) { return x; }   // device-only; declared for the host parsing pass
+inline void permute_quad(u64 *, int) {}
 // device-only below; declared for the host parsing pass
 GLF_HD u64 sbox7_nc(u64 x) { return x; }
 GLF_HD void pow_round0_consts(const u64 *, u32, u64 *) {}
 GLF_HD u64 permute_tail7(u64 *) { return 0; }
+template <class GiveUp> GLF_HD u64 permute_tail7(u64 *, GiveUp) { return 0; }
 GLF_HD u64 shfl64(u64 v, int) { return v; }
 GLF_HD u64 shfl_xor64(u64 v, int) { return v; }
 #endif

@@ -1204,46 +1204,62 @@ __global__ __launch_bounds__(256) void k_pow_batch(const u64 *st_b, const u32 *p
 // The same search for PoseidonGoldilocksConfig, restructured (round 3):
 //  * round 0 and the last linear layer collapse per candidate (poseidon.h permute_tail7; k_pow_prepare computes the twelve
 //    per-proof constants once);
-//  * a workgroup finds its next unfinished proof with ONE parallel look at all K (best, next) pairs -- thread t looks at proof
-//    (pk + t) mod K -- instead of walking past finished proofs one at a time (the tail of a 256-proof batch spent as long
-//    skipping as hashing);
+//  * work is dealt round robin over the UNFINISHED proofs: a workgroup draws a ticket (one global counter) and takes its next
+//    chunk of 256 candidates from the (ticket mod U)-th of the U proofs still open -- every thread looks at the proofs
+//    t, t + 256, ..., a wavefront scan ranks them.  What a finished search wastes is the chunks of that proof still in flight
+//    beyond the witness, so the chunks in flight must be spread evenly: workgroups that stay on "their" proof and move to the
+//    next open one when it finishes (the first form of this kernel) pile up behind runs of finished proofs, and 20 % of the
+//    candidates hashed lay beyond a witness (profiles/r03_sq_pow_batch2.txt); dealt evenly it is the ~9 % that 2^18 lanes in
+//    flight over U open proofs cost in any order;
 //  * workgroups are NOT persistent: each takes at most `chunks` chunks of 256 candidates and leaves, so the launch drains as the
 //    work runs out and the small latency-bound kernels of another sub-batch (own context and stream) find free slots between
 //    them.  The grid is sized for several times the expected work; the last `tail_from`.. workgroups stay until every proof is
 //    finished, so the search completes however unlucky it is.
+// k_b[K][12] per-proof constants, then one word: the ticket counter (k_pow_prepare zeroes it)
 __global__ __launch_bounds__(64) void k_pow_prepare(const u64 *st_b, const u32 *pos_b, u64 *k_b, u32 K) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k == 0) k_b[(size_t)K * 12] = 0;
     if (k >= K) return;
     u64 st[12], out[12];
     for (int i = 0; i < 12; i++) st[i] = st_b[(size_t)k * 12 + i];
     pos::pow_round0_consts(st, pos_b[k], out);
     for (int i = 0; i < 12; i++) k_b[(size_t)k * 12 + i] = out[i];
 }
-__global__ __launch_bounds__(256, 4) void k_pow_batch2(const u64 *k_b, const u32 *pos_b, u32 bits, unsigned long long *best,
+__device__ __forceinline__ bool pow_open(const unsigned long long *best, const unsigned long long *next, u32 q) {
+    const unsigned long long b = *(volatile const unsigned long long *)(best + q), nx = *(volatile const unsigned long long *)(next + q);
+    return nx < b && nx < (1ull << 40);
+}
+__global__ __launch_bounds__(256, 4) void k_pow_batch2(u64 *k_b, const u32 *pos_b, u32 bits, unsigned long long *best,
                                                         unsigned long long *next, u32 K, u32 chunks, u32 tail_from) {
-    __shared__ unsigned long long sh_base;
-    __shared__ u32 sh_pick;
-    const u32 t = threadIdx.x;
+    __shared__ unsigned long long sh_base, sh_ticket;
+    __shared__ u32 sh_pick, sh_wsum[4];
+    const u32 t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool persistent = blockIdx.x >= tail_from;
-    u32 pk = blockIdx.x % K;
+    unsigned long long *ticket = (unsigned long long *)(k_b + (size_t)K * 12);
     for (u32 done = 0; persistent || done < chunks; done++) {
-        // the nearest unfinished proof at or after pk (cyclically): every thread looks at one proof per window of 256
-        u32 pick = ~0u;
-        for (u32 w0 = 0; w0 < K && pick == ~0u; w0 += 256) {
-            __syncthreads();
-            if (t == 0) sh_pick = ~0u;
-            __syncthreads();
-            const u32 off = w0 + t;
-            if (off < K) {
-                const u32 q = pk + off >= K ? pk + off - K : pk + off;
-                const unsigned long long b = *(volatile unsigned long long *)(best + q), nx = *(volatile unsigned long long *)(next + q);
-                if (nx < b && nx < (1ull << 40)) atomicMin(&sh_pick, off);
-            }
-            __syncthreads();
-            pick = sh_pick;
+        // rank the open proofs: thread t owns proofs t, t + 256, ...
+        u32 mine = 0;
+        for (u32 q = t; q < K; q += 256) mine += pow_open(best, next, q) ? 1u : 0u;
+        u32 incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 v = (u32)__shfl_up((int)incl, d, 64); if ((int)lane >= d) incl += v; }
+        __syncthreads();                                            // the previous round's readers of sh_* are done
+        if (lane == 63) sh_wsum[wave] = incl;
+        if (t == 0) { sh_ticket = atomicAdd(ticket, 1ull); sh_pick = ~0u; }
+        __syncthreads();
+        u32 before = 0, open = 0;
+#pragma unroll
+        for (u32 w = 0; w < 4; w++) { if (w < wave) before += sh_wsum[w]; open += sh_wsum[w]; }
+        if (open == 0) return;                                      // every proof has its witness (or its search is exhausted)
+        const u32 want = (u32)sh_ticket % open, first = before + incl - mine;
+        if (want >= first && want < first + mine) {                 // exactly one thread; proofs may have closed since the count
+            u32 r = want - first;
+            for (u32 q = t; q < K; q += 256)
+                if (pow_open(best, next, q)) { if (r == 0) { sh_pick = q; break; } r--; }
         }
-        if (pick == ~0u) return;                                    // every proof has its witness (or its search is exhausted)
-        pk = pk + pick >= K ? pk + pick - K : pk + pick;
+        __syncthreads();
+        const u32 pk = sh_pick;
+        if (pk == ~0u) continue;                                    // it closed in between: draw again
         if (t == 0) {
             unsigned long long b = atomicAdd(next + pk, 256ull);
             if (b >= *(volatile unsigned long long *)(best + pk) || b >= (1ull << 40)) b = ~0ull;       // taken by someone else in the meantime
@@ -1258,7 +1274,9 @@ __global__ __launch_bounds__(256, 4) void k_pow_batch2(const u64 *k_b, const u32
         u64 s[12];
 #pragma unroll
         for (int r = 0; r < 12; r++) s[r] = add_cnc(k_b[(size_t)pk * 12 + r], mul_small_nc(sp, pos::mds_entry(r, (int)pos_)));
-        const u64 e7 = pos::permute_tail7(s);
+        // a witness below this whole chunk may turn up while it is being hashed: then the rest of the permutation is wasted work
+        const unsigned long long *bp = best + pk;
+        const u64 e7 = pos::permute_tail7(s, [bp, base] { return *(volatile const unsigned long long *)bp < base; });
         if (bits == 0 || (e7 >> (64 - bits)) == 0) atomicMin(best + pk, (unsigned long long)cand);
     }
 }
@@ -1285,14 +1303,14 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 // the batch proof-of-work search for PoseidonGoldilocksConfig (k_pow_prepare + k_pow_batch2); st / pos / best / next as for k_pow_batch
 int pow_batch_launch(glp_ctx *c, Tmp &tmp, const u64 *dev_pst, const u32 *dev_ppos, u32 bits, u64 *dev_best, u64 *dev_next, u32 K) {
     u64 *dev_k;
-    GLP_TRY(tmp.get(&dev_k, (size_t)K * 12));
+    GLP_TRY(tmp.get(&dev_k, (size_t)K * 12 + 1));              // + the ticket counter
     hipLaunchKernelGGL(k_pow_prepare, dim3((K + 63) / 64), dim3(64), 0, c->stream, dev_pst, dev_ppos, dev_k, K);
     GLP_HIP(hipGetLastError());
     constexpr u32 CHUNKS = 8;                                  // chunks of 256 candidates per non-persistent workgroup
     const double expected = (double)K * (bits >= 8 ? (double)(1ull << (bits - 8)) : 1.0);      // chunks: K 2^bits / 256
     const u32 tail = (u32)c->num_cus * 4;                      // these stay until every proof is finished
     const u32 body = (u32)std::min<double>(4.0 * expected / CHUNKS + 1.0, (double)(1u << 22));
-    hipLaunchKernelGGL(k_pow_batch2, dim3(body + tail), dim3(256), 0, c->stream, dev_pst == nullptr ? nullptr : dev_k, dev_ppos, bits,
+    hipLaunchKernelGGL(k_pow_batch2, dim3(body + tail), dim3(256), 0, c->stream, dev_k, dev_ppos, bits,
                        (unsigned long long *)dev_best, (unsigned long long *)dev_next, K, CHUNKS, body);
     GLP_HIP(hipGetLastError());
     return GLP_OK;

@@ -1,0 +1,29 @@
+"""Kernel timeline of ONE 256-proof zkdsa batch (no GLP_BATCH_TRACE, so no stream synchronisations between the stages).
+Run under rocprofv3 --kernel-trace; then `python profiles/zkdsa_batch_timeline.py summarize <kernel_trace.csv>` prints every kernel of the last
+batch with its start offset, duration and the idle gap in front of it."""
+import csv, os, sys, time
+if len(sys.argv) > 2 and sys.argv[1] == "summarize":
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[2]))]
+    rows.sort()
+    # the last batch = from the last k_lde_small / first kernel after the last long idle gap
+    starts = [i for i, r in enumerate(rows) if i == 0 or r[0] - rows[i - 1][1] > 300000]
+    rows = rows[starts[-1]:]
+    t0, busy, prev = rows[0][0], 0, rows[0][0]
+    for s, e, n in rows:
+        print("%9.1f us  +%7.1f gap  %8.1f us  %s" % ((s - t0) / 1e3, (s - prev) / 1e3, (e - s) / 1e3, n[:70]))
+        busy += e - s
+        prev = max(prev, e)
+    print("span %.3f ms, kernels %d, sum of durations %.3f ms" % ((prev - t0) / 1e6, len(rows), busy / 1e6))
+    sys.exit(0)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import plonky2_lib_amd as glp, plonky2_lib_amd.synth as synth
+K = 256
+rng = np.random.default_rng(1)
+descs = [synth.zkdsa_circuit(3, seed=5, private_key=synth.gl.rand(rng, 4), message=synth.gl.rand(rng, 4)) for _ in range(K)]
+ctx = glp.Context(0); gc = glp.Circuit(ctx, descs[0])
+w = np.stack([d.wires for d in descs]); pis = np.stack([d.public_inputs for d in descs])
+for _ in range(3):
+    gc.prove_batch(w, pis)
+    time.sleep(0.002)
+t = time.perf_counter(); gc.prove_batch(w, pis); print("total ms", (time.perf_counter() - t) * 1e3)

@@ -99,6 +99,19 @@ def test_batch_of_256_zkdsa_proofs(ctx, oracle):
     gc.free()
 
 
+def test_batch_of_600_zkdsa_proofs(ctx):
+    """More proofs than a proof-of-work workgroup has threads, and not a multiple of it: the search ranks the open proofs
+    t, t + 256, t + 512 per thread.  Every witness must still be the smallest one, i.e. every proof the single proof."""
+    K = 600
+    descs, wires, pis = _zkdsa_batch(K)
+    gc = glp.Circuit(ctx, descs[0])
+    proofs = gc.prove_batch(wires, pis)
+    assert gc.verify_batch(proofs).all()
+    for k in (0, 255, 256, 300, 511, 512, 599):
+        assert (proofs[k] == gc.prove(wires=wires[k], public_inputs=pis[k])).all()
+    gc.free()
+
+
 def test_batch_argument_errors(ctx):
     desc = synth.zkdsa_circuit(3)
     gc = glp.Circuit(ctx, desc)

@@ -128,6 +128,35 @@ def test_batch_edge_shapes(ctx, oracle, ncols, lg, rb, ch):
     b.free()
 
 
+@pytest.mark.parametrize("form", ["lane", "quad", "coop"])
+def test_leaf_hash_forms(oracle, form):
+    """The three forms of the Poseidon leaf hash (one sponge per lane / per quad of lanes / per 12 of 16 lanes; merkle.hip), each forced
+    over the edge shapes by the thresholds a context reads at creation: identical trees."""
+    import os
+    env = {"lane": ("0", "0"), "quad": ("0", str(1 << 40)), "coop": (str(1 << 40), str(1 << 40))}[form]
+    keys = ("GLP_MERKLE_COOP_MAX", "GLP_MERKLE_QUAD_MAX")
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ.update(dict(zip(keys, env)))
+    try:
+        c2 = glp.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    try:
+        for ncols, lg, rb, ch in [(3, 4, 3, 4), (5, 0, 3, 3), (9, 3, 3, 0), (8, 6, 3, 4), (17, 2, 1, 1), (300, 4, 3, 4), (135, 7, 3, 4)]:
+            rng = np.random.default_rng(ncols * 131 + lg)
+            vals = oracle.rand_field(rng, (ncols, 1 << lg))
+            ref = oracle.batch_from_values(vals, rb, ch)
+            b = c2.batch_from_values(vals, rb, ch)
+            _check_batch(oracle, b, ref, [0, 1, 3, 77, (1 << (lg + rb)) - 1])
+            b.free()
+    finally:
+        c2.close()
+
+
 def test_empty_batch_is_an_error(ctx):
     with pytest.raises(glp.GlpError):
         ctx.batch_from_values(np.zeros((0, 8), np.uint64), 3, 2)

@@ -5,9 +5,12 @@ import csv, os, sys, time
 if len(sys.argv) > 2 and sys.argv[1] == "summarize":
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[2]))]
     rows.sort()
-    # the last batch = from the last k_lde_small / first kernel after the last long idle gap
-    starts = [i for i, r in enumerate(rows) if i == 0 or r[0] - rows[i - 1][1] > 300000]
-    rows = rows[starts[-1]:]
+    # the last batch: around the last k_pow_batch2, bounded by idle gaps of more than 0.1 ms on either side
+    last = max(i for i, r in enumerate(rows) if "k_pow_batch2" in r[2])
+    lo = hi = last
+    while lo > 0 and rows[lo][0] - rows[lo - 1][1] < 100000: lo -= 1
+    while hi + 1 < len(rows) and rows[hi + 1][0] - rows[hi][1] < 100000: hi += 1
+    rows = rows[lo:hi + 1]
     t0, busy, prev = rows[0][0], 0, rows[0][0]
     for s, e, n in rows:
         print("%9.1f us  +%7.1f gap  %8.1f us  %s" % ((s - t0) / 1e3, (s - prev) / 1e3, (e - s) / 1e3, n[:70]))

@@ -250,8 +250,10 @@ static __device__ const pblk::BlkConst<3> PB3[1] = {pblk::make_blk<3, false>(23)
 // !MERGED: s = state entering partial round t with that round's constants already added.  MERGED: s = S-box outputs
 // of the full round before partial round t.  On return: the state entering round t+K with ITS constants added.
 // Non-canonical in and out.
-template <int K, bool MERGED>
-__device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst<K> &kc) {
+// hook(j, z): z = the state element 0 entering the S-box of the block's j-th round (j = 0..K-1); what it returns goes through the S-box
+// (the permutation: z itself; the PoseidonGate constraint evaluation: the S-box-input wire, after emitting z - wire).
+template <int K, bool MERGED, class Hook>
+__device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst<K> &kc, Hook hook) {
     constexpr pblk::Tab<K, MERGED> T = pblk::make_tab<K, MERGED>();
     // al <= (2^32-1) W + 2^32 and ah <= 2^32 + 2^32 + (2^32-1) W must fit 64 bits, value < 2^96
     static_assert(T.max_weight + 2 < (1ULL << 32), "unreduced accumulation would overflow");
@@ -263,13 +265,13 @@ __device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst
         constexpr u32 MROW0[12] = {25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};   // M[0,:]
         GLP_PB_ROW(x0, MROW0, kc.kpre, 0, 0u);
     }
-    u64 sig = sbox7_nc(x0);
+    u64 sig = sbox7_nc(hook(0, x0));
     slo[0] = (u32)sig; shi[0] = (u32)(sig >> 32);
 #pragma unroll
     for (int j = 1; j < K; j++) {           // z_j[0] -> sigma_{j+1}
         u64 z;
         GLP_PB_ROW(z, T.g0[j - 1], kc.k0[j - 1], j, T.bt[j - 1 - i][0]);
-        sig = sbox7_nc(z);
+        sig = sbox7_nc(hook(j, z));
         slo[j] = (u32)sig; shi[j] = (u32)(sig >> 32);
     }
 #pragma unroll
@@ -277,6 +279,11 @@ __device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst
         GLP_PB_ROW(s[r], T.gK[r], kc.kK[r], K, T.bt[K - 1 - i][r]);
         if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+template <int K, bool MERGED>
+__device__ __forceinline__ void partial_block_nc(u64 s[12], const pblk::BlkConst<K> &kc) {
+    partial_block_nc<K, MERGED>(s, kc, [](int, u64 z) { return z; });
 }
 
 // constants added by the full rounds' linear layers (= the NEXT round's constants): rounds 0..2 add those of rounds

@@ -396,8 +396,12 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
         }
         case GLP_GATE_POSEIDON: {
             // gates/poseidon.rs: wires = inputs 0..11, outputs 12..23, swap 24, delta 25..28, full_sbox_0(r=1..3)
-            // from 29, partial_sbox from 65, full_sbox_1 from 87.  Naive round schedule: the S-box inputs (the
-            // only place wires enter) are identical to plonky2's sparse-matrix schedule.
+            // from 29, partial_sbox from 65, full_sbox_1 from 87.  The S-box inputs are the only place wires enter, so any
+            // schedule of the linear layers gives the constraints plonky2's sparse-matrix schedule gives: this is the
+            // permutation's own gfx950 schedule (poseidon.h: non-canonical values between layers, the next round's constants
+            // folded into the linear layer, partial rounds in blocks of 3 / 4 / 4 / 4 / 4 / 3) with the wire taking the
+            // place of the state wherever an S-box is entered.
+#if defined(__HIP_DEVICE_COMPILE__)
             u32 k = 0;
             u64 st[12];
             const u64 swap = W[(size_t)24 * N];
@@ -408,31 +412,30 @@ __device__ __forceinline__ void gate_terms(const QArgs &a, const QProof &p, cons
                 st[i] = add(lhs, dl); st[i + 4] = sub(rhs, dl);
             }
             for (u32 i = 8; i < 12; i++) st[i] = W[(size_t)i * N];
-            u32 rc = 0;
+            for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[i]);
+            pos::sbox_layer_nc(st);
+            pos::mds_add_nc(st, pos::RCN.k[0]);
+            for (u32 r = 1; r < 4; r++) {
+                for (u32 i = 0; i < 12; i++) { const u64 in = W[(size_t)(29 + 12 * (r - 1) + i) * N]; EMIT(k, add_cnc(neg(in), st[i])); k++; st[i] = in; }
+                pos::sbox_layer_nc(st);
+                if (r < 3) pos::mds_add_nc(st, pos::RCN.k[r]);       // round 3's linear layer is part of the merged block
+            }
+            u32 pr = 0;                                              // partial round of the block's first S-box
+            auto wire_in = [&](int j, u64 z) {
+                const u64 in = W[(size_t)(65 + pr + (u32)j) * N];
+                EMIT(k, add_cnc(neg(in), z)); k++;
+                return in;
+            };
+            pos::partial_block_nc<3, true>(st, pos::PBM[0], wire_in); pr += 3;
+            for (int b = 0; b < 4; b++) { pos::partial_block_nc<4, false>(st, pos::PB4[b], wire_in); pr += 4; }
+            pos::partial_block_nc<3, false>(st, pos::PB3[0], wire_in);
             for (u32 r = 0; r < 4; r++) {
-                for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[rc + i]);
-                rc += 12;
-                if (r != 0)
-                    for (u32 i = 0; i < 12; i++) { const u64 in = W[(size_t)(29 + 12 * (r - 1) + i) * N]; EMIT(k, sub(st[i], in)); k++; st[i] = in; }
-                for (u32 i = 0; i < 12; i++) st[i] = pos::sbox7(st[i]);
-                pos::mds_layer(st);
+                for (u32 i = 0; i < 12; i++) { const u64 in = W[(size_t)(87 + 12 * r + i) * N]; EMIT(k, add_cnc(neg(in), st[i])); k++; st[i] = in; }
+                pos::sbox_layer_nc(st);
+                pos::mds_add_nc(st, r < 3 ? pos::RCN.k[4 + r] : pos::RC_ZERO);
             }
-            for (u32 r = 0; r < 22; r++) {
-                for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[rc + i]);
-                rc += 12;
-                const u64 in = W[(size_t)(65 + r) * N];
-                EMIT(k, sub(st[0], in)); k++;
-                st[0] = pos::sbox7(in);
-                pos::mds_layer(st);
-            }
-            for (u32 r = 0; r < 4; r++) {
-                for (u32 i = 0; i < 12; i++) st[i] = add(st[i], pos::RC[rc + i]);
-                rc += 12;
-                for (u32 i = 0; i < 12; i++) { const u64 in = W[(size_t)(87 + 12 * r + i) * N]; EMIT(k, sub(st[i], in)); k++; st[i] = in; }
-                for (u32 i = 0; i < 12; i++) st[i] = pos::sbox7(st[i]);
-                pos::mds_layer(st);
-            }
-            for (u32 i = 0; i < 12; i++) { EMIT(k, sub(st[i], W[(size_t)(12 + i) * N])); k++; }
+            for (u32 i = 0; i < 12; i++) { EMIT(k, add_cnc(neg(W[(size_t)(12 + i) * N]), st[i])); k++; }
+#endif
             break;
         }
         case GLP_GATE_U32_INTERLEAVE: {

@@ -1,6 +1,7 @@
-"""Kernel timeline of ONE 256-proof zkdsa batch (no GLP_BATCH_TRACE, so no stream synchronisations between the stages).
-Run under rocprofv3 --kernel-trace; then `python profiles/zkdsa_batch_timeline.py summarize <kernel_trace.csv>` prints every kernel of the last
-batch with its start offset, duration and the idle gap in front of it."""
+"""Kernel timeline of ONE glp_prove_batch call (no GLP_BATCH_TRACE, so no stream synchronisations between the stages):
+    rocprofv3 --kernel-trace --output-format csv -d <dir> -- python3 profiles/batch_timeline.py [zkdsa | smt | keccak]      (256 / 256 / 16 proofs)
+    python profiles/batch_timeline.py summarize <kernel_trace.csv>
+prints every kernel of the last batch with its start offset, the idle gap in front of it and its duration."""
 import csv, os, sys, time
 if len(sys.argv) > 2 and sys.argv[1] == "summarize":
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[2]))]
@@ -21,9 +22,21 @@ if len(sys.argv) > 2 and sys.argv[1] == "summarize":
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import plonky2_lib_amd as glp, plonky2_lib_amd.synth as synth
-K = 256
+what = sys.argv[1] if len(sys.argv) > 1 else "zkdsa"
 rng = np.random.default_rng(1)
-descs = [synth.zkdsa_circuit(3, seed=5, private_key=synth.gl.rand(rng, 4), message=synth.gl.rand(rng, 4)) for _ in range(K)]
+if what == "smt":
+    from plonky2_lib_amd import gadgets
+    tree = gadgets.SparseMerkleTree()
+    keys = [tuple(int(x) for x in rng.integers(0, 1 << 32, 4)) for _ in range(128)]
+    for k in keys:
+        tree.insert(k, tuple(int(x) for x in rng.integers(1, 1 << 32, 4)))
+    pick = [k for k in (keys[int(rng.integers(0, 128))] for _ in range(2000)) if len(tree.find(k)["siblings"]) < 16][:256]
+    descs = [gadgets.smt_inclusion_circuit(tree, k, public=True) for k in pick]
+elif what == "keccak":
+    from plonky2_lib_amd import gadgets
+    descs = [gadgets.keccak256_circuit(bytes(rng.integers(0, 256, int(rng.integers(0, 136)), dtype=np.uint8))) for _ in range(16)]
+else:
+    descs = [synth.zkdsa_circuit(3, seed=5, private_key=synth.gl.rand(rng, 4), message=synth.gl.rand(rng, 4)) for _ in range(256)]
 ctx = glp.Context(0); gc = glp.Circuit(ctx, descs[0])
 w = np.stack([d.wires for d in descs]); pis = np.stack([d.public_inputs for d in descs])
 for _ in range(3):

@@ -10,7 +10,7 @@ python bench.py --workload smt --steps 3 --no-cpu-baseline 2>/dev/null > gpurun_
 python bench.py --workload keccak256 --steps 3 --no-cpu-baseline 2>/dev/null > gpurun_out/r03b_keccak.json
 GLP_BATCH_TRACE=1 python profiles/zkdsa_batch_trace.py > gpurun_out/r03b_trace.txt 2>&1
 bash profiles/pow_ab.sh final > gpurun_out/r03b_pow.txt 2>&1
-export TMPDIR=/tmp; R=$(pwd); mkdir -p gpurun_out/tl2 && cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl2 -- python3 $R/profiles/zkdsa_batch_timeline.py > $R/gpurun_out/tl2.out 2>&1; cd $R
+export TMPDIR=/tmp; R=$(pwd); mkdir -p gpurun_out/tl2 && cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl2 -- python3 $R/profiles/batch_timeline.py > $R/gpurun_out/tl2.out 2>&1; cd $R
 python3 - <<'PY'
 import json,glob
 for f in sorted(glob.glob('gpurun_out/r03b_*.json')):

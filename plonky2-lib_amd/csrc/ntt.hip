@@ -987,6 +987,45 @@ __global__ __launch_bounds__(256) void k_intt_small(const u64 *__restrict__ in, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Transforms of 32..256 points (lg 5..8: the 2^7-row SMT trace, the middle FRI layers): ALL cosets of a column -- and several columns
+// when that is still under 1024 elements -- in one LDS tile, every radix-2 stage over the whole tile.  k_lde_contig walks the cosets of
+// a column one after the other (for 2^7 points: half the workgroup idle, nine barriers per coset) and needs a grid row per column:
+// 256 SMT proofs are 34 560 wire columns, four launches and 0.72 ms; the output of a column group is one contiguous run.
+// ------------------------------------------------------------------------------------------
+template <int LGB>
+__global__ __launch_bounds__(TPB) void k_lde_mid(const u64 *__restrict__ coeffs, u64 *__restrict__ out, const u64 *__restrict__ tw_B,
+                                                 const u64 *__restrict__ pre, u32 ncols, int rate_bits, int cpb_lg) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    constexpr int B = 1 << LGB;
+    const int tid = threadIdx.x, lgPC = LGB + rate_bits, E = 1 << (lgPC + cpb_lg);
+    u64 *tile = smem, *tw = smem + E;
+    const size_t col0 = (size_t)blockIdx.x << cpb_lg;
+    for (int j = tid; j < (B >> 1); j += TPB) tw[j] = tw_B[j];
+    for (int idx = tid; idx < E; idx += TPB) {
+        const size_t col = col0 + (size_t)(idx >> lgPC);
+        const int pl = idx & (B - 1), r = (idx >> LGB) & ((1 << rate_bits) - 1);
+        tile[idx] = col < ncols ? mul(coeffs[col * B + pl], pre[(size_t)r * B + pl]) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < LGB; s++) {
+        const int half = 1 << s;
+        for (int bf = tid; bf < (E >> 1); bf += TPB) {
+            const int j2 = bf & ((B >> 1) - 1), lo = j2 & (half - 1);
+            const int j = ((bf >> (LGB - 1)) << LGB) | ((j2 >> s) << (s + 1)) | lo;
+            const u64 u = tile[j];
+            const u64 v = mul(tile[j + half], tw[lo << (LGB - 1 - s)]);
+            tile[j] = add(u, v);
+            tile[j + half] = sub(u, v);
+        }
+        __syncthreads();
+    }
+    const size_t live = (size_t)ncols << lgPC, base = col0 << lgPC;      // (col R + r) n + q of the group's first element
+    for (int idx = tid; idx < E; idx += TPB)
+        if (base + idx < live) out[base + idx] = tile[idx];
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
 static size_t contig_lds_bytes(int lgB) { return (((size_t)1 << lgB) + ((size_t)1 << lgB) / 2 + 1 + 64 + 64 + 16) * sizeof(u64); }
@@ -1010,12 +1049,30 @@ static int lde_small(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols,
     GLP_HIP(hipGetLastError());
     return GLP_OK;
 }
+static int lde_mid(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift) {
+    if (ncols == 0) return GLP_OK;
+    LdePlan *lp;
+    GLP_TRY(get_lde_plan(c, lg, rate_bits, shift, &lp));
+    const NttPlan *np = lp->ntt;
+    const int cpb_lg = std::max(0, 10 - lg - rate_bits);                // columns per workgroup: up to 1024 elements in the tile
+    const dim3 g((ncols + (1u << cpb_lg) - 1) >> cpb_lg), b(TPB);
+    const size_t lds = (((size_t)1 << (lg + rate_bits + cpb_lg)) + ((size_t)1 << lg) / 2) * sizeof(u64);
+    switch (lg) {
+    case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lde_mid<5>), g, b, lds, c->stream, dev_coeffs, dev_lde, np->tw_B, lp->pre, ncols, rate_bits, cpb_lg); break;
+    case 6: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lde_mid<6>), g, b, lds, c->stream, dev_coeffs, dev_lde, np->tw_B, lp->pre, ncols, rate_bits, cpb_lg); break;
+    case 7: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lde_mid<7>), g, b, lds, c->stream, dev_coeffs, dev_lde, np->tw_B, lp->pre, ncols, rate_bits, cpb_lg); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lde_mid<8>), g, b, lds, c->stream, dev_coeffs, dev_lde, np->tw_B, lp->pre, ncols, rate_bits, cpb_lg); break;
+    }
+    GLP_HIP(hipGetLastError());
+    return GLP_OK;
+}
 // grid.y carries (column, coset plane, outer block): at most 65535.  Wide inputs (the K-proof batches of glp_prove_batch:
 // K * num_wires columns) go through in column chunks.
 int lde_coeffs(glp_ctx *c, const u64 *dev_coeffs, u64 *dev_lde, u32 ncols, int lg, int rate_bits, u64 shift) {
     if (lg < 0 || lg > NTT_MAX_LG) return set_error(GLP_ERR_UNSUPPORTED, "log_n=%d outside the supported range 0..%d", lg, NTT_MAX_LG);
     if (rate_bits < 0 || rate_bits > 4) return set_error(GLP_ERR_UNSUPPORTED, "rate_bits=%d outside 0..4", rate_bits);
     if (lg <= 4) return lde_small(c, dev_coeffs, dev_lde, ncols, lg, rate_bits, shift);       // one thread per (column, coset)
+    if (lg <= 8) return lde_mid(c, dev_coeffs, dev_lde, ncols, lg, rate_bits, shift);         // all cosets of a column in one tile
     const u32 per = 65535u >> (rate_bits + (lg > c->two_pass_lg ? lg - NTT_INNER_LG : 0));
     const size_t n = (size_t)1 << lg;
     for (u32 c0 = 0; c0 < ncols; c0 += per)

@@ -390,35 +390,41 @@ __device__ __forceinline__ u64 permute_tail7(u64 s[12], GiveUp give_up) {
 }
 __device__ __forceinline__ u64 permute_tail7(u64 s[12]) { return permute_tail7(s, [] { return false; }); }
 // ---- one permutation on 12 lanes --------------------------------------------------------------------
-// Latency form for the small levels near the top of a Merkle tree and the small FRI layers, where there are far
-// fewer hashes than lanes: lane l (0..11 of a 16-lane group) owns state element l, S-boxes run 12-wide, and the
-// circulant MDS row of lane l gathers x[(i + l) % 12] from its neighbours with wavefront shuffles (ds_bpermute).
-// About 5x lower latency per hash than one-state-per-lane; lower throughput (partial rounds idle 11 lanes), so the
-// big levels keep the one-state-per-lane kernel.  x: canonical in, canonical out; all 64 lanes must call it.
-__device__ __forceinline__ u64 permute_coop(u64 x, int l /* lane in group, 0..15 */, int group_base /* first lane of the group in the wave */) {
-    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+// Latency form for the small levels near the top of a Merkle tree, the small FRI layers and the Fiat-Shamir transcripts of a batch, where
+// there are far fewer hashes than lanes: lane l (0..11 of a 16-lane group = one DPP row) owns state element l and S-boxes run 12-wide.
+// The linear layer is row l of the matrix against the whole state: element j reaches every lane of the row by a DPP row broadcast
+// (v_mov_b64 row_newbcast:j, no LDS) and is multiplied by the lane's own coefficient M[l][j], held in twelve registers.
+// (The first form rotated the data instead -- 24 ds_bpermute per round with their LDS latency: ~16 us per permutation against ~11.)
+// A wave running alone pays ~4 clocks per VALU instruction and 8 per multiply-add, so what counts is the instruction count of one lane:
+// ~120 per round here against ~470 with one state per lane.  Lower throughput (partial rounds idle 11 lanes), so the big levels keep the
+// one-state-per-lane kernel.  x: canonical in, canonical out; all 64 lanes must call it.
+static __device__ const u32 MDS_C24[24] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20, 17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+template <int J> __device__ __forceinline__ u64 row_bcast(u64 v) {     // every lane of a 16-lane row receives lane J's v (v_mov_b64_dpp)
+    return (u64)__builtin_amdgcn_update_dpp((long long)0, (long long)v, 0x150 + J, 0xf, 0xf, true);
+}
+template <int J> __device__ __forceinline__ void coop_row_terms(u64 &al, u64 &ah, u64 x, const u32 (&cf)[12]) {
+    if constexpr (J < 12) {
+        const u64 b = row_bcast<J>(x);
+        al += (u64)(u32)b * cf[J];
+        ah += (u64)(u32)(b >> 32) * cf[J];
+        coop_row_terms<J + 1>(al, ah, x, cf);
+    }
+}
+__device__ __forceinline__ u64 permute_coop(u64 x, int l /* lane in group, 0..15 */, int /* group_base: first lane of the group in the wave */) {
     const int ll = l < 12 ? l : 0;
+    u32 cf[12];                                                 // cf[j] = M[l][j] = C[(j - l) mod 12] (+ 8 at [0][0])
+#pragma unroll
+    for (int j = 0; j < 12; j++) cf[j] = MDS_C24[12 + j - ll];
+    if (l == 0) cf[0] += 8;
     x = add(x, RC[ll]);
     for (int r = 0; r < 30; r++) {
         const bool full = r < 4 || r >= 26;
         const u64 sb = sbox7_nc(x);
         if (full || l == 0) x = sb;
         const u64 rcn = r < 29 ? RC[12 * (r + 1) + ll] : 0;
-        const u32 xlo = (u32)x, xhi = (u32)(x >> 32);
-        u64 al = (u32)rcn;
-        u32 hi_g[12];
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            int src = ll + i; src = src >= 12 ? src - 12 : src;
-            const u32 lo_i = (u32)__shfl((int)xlo, group_base + src, 64);
-            hi_g[i] = (u32)__shfl((int)xhi, group_base + src, 64);
-            al += (u64)lo_i * C[i];
-        }
-        if (l == 0) al += (u64)xlo * 8;
-        u64 ah = (al >> 32) + (rcn >> 32);
-#pragma unroll
-        for (int i = 0; i < 12; i++) ah += (u64)hi_g[i] * C[i];
-        if (l == 0) ah += (u64)xhi * 8;
+        u64 al = (u32)rcn, ah = rcn >> 32;
+        coop_row_terms<0>(al, ah, x, cf);
+        ah += al >> 32;
         x = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
     }
     return canon(x);

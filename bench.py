@@ -408,9 +408,16 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
         ctx = glp.Context(local_rank)
         sub = descs[t::nthr]
         circuit = glp.Circuit(ctx, descs[0]) if sub else None     # one circuit, many witnesses
-        wires = np.stack([d.wires for d in sub]) if sub else None
-        pis = np.stack([d.public_inputs for d in sub]) if sub else None
-        out = np.empty((len(sub), circuit.proof_words), np.uint64) if sub else None      # proofs land here every step
+        # witnesses, public inputs and the proofs' landing buffer in page-locked memory (glp_host_alloc), as a host that proves batch
+        # after batch would hold them: both copies of a batch are plain DMA
+        wires = pis = out = None
+        if sub:
+            wires = ctx.host_alloc((len(sub),) + tuple(sub[0].wires.shape))
+            pis = ctx.host_alloc((len(sub), len(sub[0].public_inputs)))
+            for i, d in enumerate(sub):
+                wires[i] = d.wires
+                pis[i] = d.public_inputs
+            out = ctx.host_alloc((len(sub), circuit.proof_words))                       # proofs land here every step
         workers.append([ctx, circuit, sub, wires, pis, out])
 
     def step():
@@ -485,7 +492,7 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all, "prove_plus_verify": pv,
             "config": {"workload": "%d messages through the reference's Keccak-256 circuit [REF src/hash/keccak256.rs:79-165], %d rate block(s): "
                                    "2^%d rows x 135 wires (%d gate rows: %s), %s, 8 public inputs = the digest; %s, %d in flight per GPU, "
-                                   "witnesses from host memory" %
+                                   "witnesses from (and proofs into) page-locked host memory" %
                                    (a.batch, a.keccak_blocks, d0.degree_bits, d0.gadget_rows, ", ".join("%s x%d" % kv for kv in d0.gate_ops.items()),
                                     "KeccakGoldilocksConfig" if a.hasher == "keccak" else "PoseidonGoldilocksConfig",
                                     "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
@@ -501,7 +508,7 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all, "prove_plus_verify": pv,
             "config": {"workload": "%d (non-)membership proofs of one 128-key tree through the reference's 16-level inclusion circuit "
                                    "[REF src/smt/gadgets/verify/verify_smt.rs:214-307]: 2^%d rows x 135 wires (%d gate rows: %s), 12 public inputs "
-                                   "(root, key, value); %s, %d in flight per GPU, witnesses from host memory" %
+                                   "(root, key, value); %s, %d in flight per GPU, witnesses from (and proofs into) page-locked host memory" %
                                    (a.batch, d0.degree_bits, d0.gadget_rows, ", ".join("%s x%d" % kv for kv in d0.gate_ops.items()),
                                     "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
                        "note": "circuit and native tree are this repository's Python restatements of the reference's gadget and tree (gate placement is "
@@ -514,7 +521,7 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all, "prove_plus_verify": pv,
             "config": {"workload": "%d zkdsa proofs (2^3 rows, 4 PoseidonGate rows, 12 public inputs, 16 proof-of-work bits each), %s, %d in "
-                                   "flight per GPU, witnesses from host memory" %
+                                   "flight per GPU, witnesses from (and proofs into) page-locked host memory" %
                                    (a.batch, "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
                        "parallelism": "independent proofs sharded over ranks, no collective"}}))
     for w in workers:

@@ -49,8 +49,11 @@ def parse():
     ap.add_argument("--keccak-blocks", type=int, default=1, help="keccak256: rate blocks of the circuit (1: 2^13 rows, 4: 2^15 rows)")
     ap.add_argument("--hasher", default="poseidon", choices=["poseidon", "keccak"],
                     help="keccak256: PoseidonGoldilocksConfig or KeccakGoldilocksConfig [REF src/hash/keccak256.rs:216,281]")
-    ap.add_argument("--threads", type=int, default=2, help="zkdsa-batch: sub-batches in flight per GPU (own context / stream / host thread each)")
-    ap.add_argument("--sub-batch", type=int, default=128, help="zkdsa-batch: proofs per glp_prove_batch call")
+    ap.add_argument("--threads", type=int, default=1, help="zkdsa-batch / smt / keccak256: sub-batches in flight per GPU (own context / stream / host thread each); "
+                    "1 is the steadiest for one batch of 256 (9.4-9.5 ms; two of 128 in flight: 10.3-10.7 ms, but 18.8 k instead of 17.3 k proofs/s "
+                    "proved AND verified); a 2048-proof batch wants 4")
+    ap.add_argument("--sub-batch", type=int, default=256, help="zkdsa-batch / smt: proofs per glp_prove_batch call")
+    ap.add_argument("--pinned", action="store_true", help="zkdsa-batch / keccak256 / smt: host buffers from glp_host_alloc (page-locked) instead of ordinary memory, for comparison")
     ap.add_argument("--per-proof", action="store_true", help="zkdsa-batch: one glp_prove call per proof (the round-1 path), for comparison")
     ap.add_argument("--circuit", default="real", choices=["real", "stand-in"],
                     help="ecdsa: real = the reference's secp256k1 verification circuit rebuilt gadget for gadget (plonky2-lib_amd/gadgets_ecdsa.py; "
@@ -408,16 +411,17 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
         ctx = glp.Context(local_rank)
         sub = descs[t::nthr]
         circuit = glp.Circuit(ctx, descs[0]) if sub else None     # one circuit, many witnesses
-        # witnesses, public inputs and the proofs' landing buffer in page-locked memory (glp_host_alloc), as a host that proves batch
-        # after batch would hold them: both copies of a batch are plain DMA
+        # --pinned: witnesses, public inputs and the proofs' landing buffer in page-locked memory (glp_host_alloc).  Measured: no gain with one
+        # sub-batch in flight (9.4-9.6 ms either way) and a LOSS with two or four (profiles/r03_zkdsa_batch.txt), so ordinary memory is the default
         wires = pis = out = None
         if sub:
-            wires = ctx.host_alloc((len(sub),) + tuple(sub[0].wires.shape))
-            pis = ctx.host_alloc((len(sub), len(sub[0].public_inputs)))
+            halloc = ctx.host_alloc if a.pinned else (lambda shape: np.empty(shape, np.uint64))
+            wires = halloc((len(sub),) + tuple(sub[0].wires.shape))
+            pis = halloc((len(sub), len(sub[0].public_inputs)))
             for i, d in enumerate(sub):
                 wires[i] = d.wires
                 pis[i] = d.public_inputs
-            out = ctx.host_alloc((len(sub), circuit.proof_words))                       # proofs land here every step
+            out = halloc((len(sub), circuit.proof_words))                               # proofs land here every step
         workers.append([ctx, circuit, sub, wires, pis, out])
 
     def step():
@@ -492,7 +496,7 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all, "prove_plus_verify": pv,
             "config": {"workload": "%d messages through the reference's Keccak-256 circuit [REF src/hash/keccak256.rs:79-165], %d rate block(s): "
                                    "2^%d rows x 135 wires (%d gate rows: %s), %s, 8 public inputs = the digest; %s, %d in flight per GPU, "
-                                   "witnesses from (and proofs into) page-locked host memory" %
+                                   "witnesses from host memory" %
                                    (a.batch, a.keccak_blocks, d0.degree_bits, d0.gadget_rows, ", ".join("%s x%d" % kv for kv in d0.gate_ops.items()),
                                     "KeccakGoldilocksConfig" if a.hasher == "keccak" else "PoseidonGoldilocksConfig",
                                     "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
@@ -508,7 +512,7 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all, "prove_plus_verify": pv,
             "config": {"workload": "%d (non-)membership proofs of one 128-key tree through the reference's 16-level inclusion circuit "
                                    "[REF src/smt/gadgets/verify/verify_smt.rs:214-307]: 2^%d rows x 135 wires (%d gate rows: %s), 12 public inputs "
-                                   "(root, key, value); %s, %d in flight per GPU, witnesses from (and proofs into) page-locked host memory" %
+                                   "(root, key, value); %s, %d in flight per GPU, witnesses from host memory" %
                                    (a.batch, d0.degree_bits, d0.gadget_rows, ", ".join("%s x%d" % kv for kv in d0.gate_ops.items()),
                                     "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
                        "note": "circuit and native tree are this repository's Python restatements of the reference's gadget and tree (gate placement is "
@@ -521,7 +525,7 @@ def zkdsa_batch(a, grp, local_rank, glp, synth, gdist, torch):
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64 (Goldilocks, 64-bit modular integer)", "data": "synthetic", "verified": ok_all, "prove_plus_verify": pv,
             "config": {"workload": "%d zkdsa proofs (2^3 rows, 4 PoseidonGate rows, 12 public inputs, 16 proof-of-work bits each), %s, %d in "
-                                   "flight per GPU, witnesses from (and proofs into) page-locked host memory" %
+                                   "flight per GPU, witnesses from host memory" %
                                    (a.batch, "one glp_prove per proof" if a.per_proof else "glp_prove_batch in sub-batches of %d" % a.sub_batch, nthr),
                        "parallelism": "independent proofs sharded over ranks, no collective"}}))
     for w in workers:

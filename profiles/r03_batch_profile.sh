@@ -19,3 +19,8 @@ for f in sorted(glob.glob('gpurun_out/r03b_*.json')):
         print(f.split('/')[-1], 'value %.0f %s  ms_per_step %.3f  verified %s  prove+verify %s' % (d['value'], d['unit'], d['ms_per_step'], d.get('verified'), json.dumps(d.get('prove_plus_verify'))[:120]))
     except Exception as e: print(f, 'ERR', e)
 PY
+for W in zkdsa smt keccak; do
+  mkdir -p gpurun_out/tlf_$W && cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tlf_$W -- python3 $R/profiles/batch_timeline.py $W > $R/gpurun_out/tlf_$W.out 2>&1; cd $R
+  python3 profiles/batch_timeline.py summarize $(find gpurun_out/tlf_$W -name "*kernel_trace.csv" | head -1) | cut -c1-150 > gpurun_out/r03b_timeline_$W.txt
+  tail -1 gpurun_out/r03b_timeline_$W.txt
+done

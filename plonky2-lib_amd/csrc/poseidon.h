@@ -74,73 +74,6 @@ GLF_HD u32 mds_entry(int r, int i) {     // M[r][i] of the circulant-plus-diagon
     constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     return C[(i - r + 12) % 12] + (r == 0 && i == 0 ? 8u : 0u);
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-// ---- gfx950 schedule ---------------------------------------------------------------------------
-// Same permutation, restructured for the VALU (the kernel is integer-issue bound, not HBM bound):
-//  * values between layers are ANY u64 congruent to the field element (no canonicalisation until
-//    the end), so no layer contains a compare-and-subtract;
-//  * the next round's constant layer is folded into the MDS accumulators' initial value, so the
-//    only stand-alone modular additions are the 12 of round 0;
-//  * reductions are written on 32-bit limbs with carry builtins (v_add_co/v_addc chains) instead
-//    of 64-bit compares + selects.
-// Measured (profiles/r01_ubench_int_issue.txt): v_mad_u64_u32 and v_lshl_add_u64 issue at half
-// rate on gfx950, so one MDS row (24 multiply-adds by 6-bit constants + one 96-bit fold) is the
-// dominant cost.
-static __device__ const u64 RC_ZERO[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-
-__device__ __forceinline__ u64 sbox7_nc(u64 x) {
-#ifdef GLP_SBOX_PLAIN_MUL
-    const u64 x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
-    return mul_nc(x3, x4);
-#else
-    const u64 x2 = mul_nc_cc(x, x), x4 = mul_nc_cc(x2, x2), x3 = mul_nc_cc(x, x2);
-    return mul_nc_cc(x3, x4);
-#endif
-}
-// 12 S-boxes in groups of SBOX_GROUP: the scheduling barrier keeps hipcc from interleaving all 12 chains (which
-// costs ~50 VGPRs and a wave of occupancy); within a group the chains still overlap
-#ifndef GLP_MDS_GROUP
-#define GLP_MDS_GROUP 4
-#endif
-#ifndef GLP_SBOX_GROUP
-#define GLP_SBOX_GROUP 4
-#endif
-__device__ __forceinline__ void sbox_layer_nc(u64 s[12]) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        s[i] = sbox7_nc(s[i]);
-        if (i % GLP_SBOX_GROUP == GLP_SBOX_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-// s <- MDS * s + rc   (rc = the NEXT round's constants), inputs and outputs non-canonical
-__device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
-    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    u32 lo[12], hi[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
-    // 16 and 2 held in SGPRs the compiler cannot see through: otherwise it turns those terms into
-    // v_lshl_add_u64 on a (limb, 0) register pair it has to build with two moves (3.75 issue slots against 1.75)
-    u32 c16 = 16, c2 = 2;
-    asm volatile("" : "+s"(c16), "+s"(c2));
-#pragma unroll
-    for (int r = 0; r < 12; r++) {
-        // low halves first; the high-half chain then starts from the low chain's overflow, so the 96-bit row value
-        // (ah : low 32 bits of al) needs no carry combine
-        u64 al = (u64)(u32)rc[r] + (u64)lo[r] * (r == 0 ? C[0] + 8 : C[0]);
-        asm("" : "+v"(al));            // keep the constant as the first multiply-add's addend (no separate 64-bit add)
-#pragma unroll
-        for (int i = 1; i < 12; i++) al += (u64)lo[(i + r) % 12] * (C[i] == 16 ? c16 : C[i] == 2 ? c2 : C[i]);
-        u64 ah = (al >> 32) + (rc[r] >> 32);
-#pragma unroll
-        for (int i = 0; i < 12; i++) ah += (u64)hi[(i + r) % 12] * (i == 0 && r == 0 ? C[0] + 8 : C[i] == 16 ? c16 : C[i] == 2 ? c2 : C[i]);
-#ifdef GLP_MDS_FOLD_C
-        s[r] = fold96_c((ah << 32) | (u32)al, (u32)(ah >> 32));
-#else
-        s[r] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
-#endif
-        if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-    }
-}
 // ---- partial rounds, K at a time -------------------------------------------------------------------
 // A partial round is x <- M (E x + e0 sbox(x0)) + c  (E zeroes coordinate 0, c = the next round's constants):
 // linear except for ONE S-box, so K of them compose into
@@ -227,6 +160,74 @@ template <int K, bool MERGED> constexpr BlkConst<K> make_blk(int first_round) {
     return b;
 }
 }  // namespace pblk
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 schedule ---------------------------------------------------------------------------
+// Same permutation, restructured for the VALU (the kernel is integer-issue bound, not HBM bound):
+//  * values between layers are ANY u64 congruent to the field element (no canonicalisation until
+//    the end), so no layer contains a compare-and-subtract;
+//  * the next round's constant layer is folded into the MDS accumulators' initial value, so the
+//    only stand-alone modular additions are the 12 of round 0;
+//  * reductions are written on 32-bit limbs with carry builtins (v_add_co/v_addc chains) instead
+//    of 64-bit compares + selects.
+// Measured (profiles/r01_ubench_int_issue.txt): v_mad_u64_u32 and v_lshl_add_u64 issue at half
+// rate on gfx950, so one MDS row (24 multiply-adds by 6-bit constants + one 96-bit fold) is the
+// dominant cost.
+static __device__ const u64 RC_ZERO[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+__device__ __forceinline__ u64 sbox7_nc(u64 x) {
+#ifdef GLP_SBOX_PLAIN_MUL
+    const u64 x2 = mul_nc(x, x), x4 = mul_nc(x2, x2), x3 = mul_nc(x, x2);
+    return mul_nc(x3, x4);
+#else
+    const u64 x2 = mul_nc_cc(x, x), x4 = mul_nc_cc(x2, x2), x3 = mul_nc_cc(x, x2);
+    return mul_nc_cc(x3, x4);
+#endif
+}
+// 12 S-boxes in groups of SBOX_GROUP: the scheduling barrier keeps hipcc from interleaving all 12 chains (which
+// costs ~50 VGPRs and a wave of occupancy); within a group the chains still overlap
+#ifndef GLP_MDS_GROUP
+#define GLP_MDS_GROUP 4
+#endif
+#ifndef GLP_SBOX_GROUP
+#define GLP_SBOX_GROUP 4
+#endif
+__device__ __forceinline__ void sbox_layer_nc(u64 s[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        s[i] = sbox7_nc(s[i]);
+        if (i % GLP_SBOX_GROUP == GLP_SBOX_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// s <- MDS * s + rc   (rc = the NEXT round's constants), inputs and outputs non-canonical
+__device__ __forceinline__ void mds_add_nc(u64 s[12], const u64 *rc) {
+    constexpr u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    // 16 and 2 held in SGPRs the compiler cannot see through: otherwise it turns those terms into
+    // v_lshl_add_u64 on a (limb, 0) register pair it has to build with two moves (3.75 issue slots against 1.75)
+    u32 c16 = 16, c2 = 2;
+    asm volatile("" : "+s"(c16), "+s"(c2));
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        // low halves first; the high-half chain then starts from the low chain's overflow, so the 96-bit row value
+        // (ah : low 32 bits of al) needs no carry combine
+        u64 al = (u64)(u32)rc[r] + (u64)lo[r] * (r == 0 ? C[0] + 8 : C[0]);
+        asm("" : "+v"(al));            // keep the constant as the first multiply-add's addend (no separate 64-bit add)
+#pragma unroll
+        for (int i = 1; i < 12; i++) al += (u64)lo[(i + r) % 12] * (C[i] == 16 ? c16 : C[i] == 2 ? c2 : C[i]);
+        u64 ah = (al >> 32) + (rc[r] >> 32);
+#pragma unroll
+        for (int i = 0; i < 12; i++) ah += (u64)hi[(i + r) % 12] * (i == 0 && r == 0 ? C[0] + 8 : C[i] == 16 ? c16 : C[i] == 2 ? c2 : C[i]);
+#ifdef GLP_MDS_FOLD_C
+        s[r] = fold96_c((ah << 32) | (u32)al, (u32)(ah >> 32));
+#else
+        s[r] = fold96_nc((ah << 32) | (u32)al, (u32)(ah >> 32));
+#endif
+        if (r % GLP_MDS_GROUP == GLP_MDS_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // rounds 3(linear layer)+4..6 merged, 7..22 as four blocks of 4, 23..25 as one block of 3
 static __device__ const pblk::BlkConst<3> PBM[1] = {pblk::make_blk<3, true>(4)};
@@ -487,7 +488,79 @@ __device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
     return ((u64)hi << 32) | lo;
 }
 #else
-inline void permute(u64 s[12]) { permute_ref(s); }
+// ---- host schedule (the Fiat-Shamir transcripts of glp_prove / glp_verify and the verifiers' Merkle paths) -----------------------------
+// Same permutation as permute_ref with the 22 partial rounds in the blocks of namespace pblk (3 merged with round 3's linear layer, 4 x 4, 3):
+// one 12-row product per block instead of one per round.  What bounds a block on a CPU core is its chain of S-boxes (each four dependent
+// 64 x 64 multiplications and reductions) with a 24-term row between two of them: 3.5 -> 2.3 us per permutation on the build machine.
+// Full rounds keep the reference layers (hipcc's host pass vectorises mds_layer's unrolled rows; branch-free reductions measured slower).
+namespace host {
+inline u64 sbox(u64 x) { return sbox7(x); }              // any u64 in, canonical out (glf::mul: rarely-taken branches predict well on a CPU)
+// (al + 2^32 ah + k) mod p as some u64: al, ah unreduced sums of 32-bit-half products with total weight < 2^32
+inline u64 fold(u64 al, u64 ah, u64 k) {
+    al += (u32)k;
+    const u64 h = ah + (al >> 32) + (k >> 32);
+    const u64 l = (h << 32) | (u32)al, t1 = (h >> 32) * EPS;
+    u64 t2 = l + t1;
+    if (t2 < t1) t2 += EPS;
+    return t2;
+}
+// s <- MDS s + rc   (rc canonical: the next round's constants, or zeros); canonical out
+inline void mds_add(u64 s[12], const u64 *rc) {
+    mds_layer(s);
+    for (int i = 0; i < 12; i++) s[i] = add(s[i], rc[i]);
+}
+// K partial rounds as one block (the tables of namespace pblk, shared with the gfx950 schedule): s = the state entering partial round t with
+// that round's constants added (MERGED: the S-box outputs of the full round before it); on return the state entering round t + K with its
+// constants.  Every row is an unreduced sum of 32-bit-half products (weights < 2^32) folded once.
+template <int K, bool MERGED>
+inline void partial_block(u64 s[12], const pblk::BlkConst<K> &kc) {
+    constexpr pblk::Tab<K, MERGED> T = pblk::make_tab<K, MERGED>();
+    static_assert(T.max_weight + 2 < (1ULL << 32), "unreduced accumulation would overflow");
+    u32 lo[12], hi[12], slo[K], shi[K];
+    for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    u64 x0 = s[0];
+    if (MERGED) {
+        constexpr u32 MROW0[12] = {25, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+        u64 al = 0, ah = 0;
+        _Pragma("unroll") for (int c = 0; c < 12; c++) { al += (u64)lo[c] * MROW0[c]; ah += (u64)hi[c] * MROW0[c]; }
+        x0 = fold(al, ah, kc.kpre);
+    }
+    u64 sig = sbox(x0);
+    slo[0] = (u32)sig; shi[0] = (u32)(sig >> 32);
+    _Pragma("unroll") for (int j = 1; j < K; j++) {
+        u64 al = 0, ah = 0;
+        _Pragma("unroll") for (int c = 0; c < 12; c++) { al += (u64)lo[c] * T.g0[j - 1][c]; ah += (u64)hi[c] * T.g0[j - 1][c]; }
+        _Pragma("unroll") for (int i = 0; i < j; i++) { al += (u64)slo[i] * T.bt[j - 1 - i][0]; ah += (u64)shi[i] * T.bt[j - 1 - i][0]; }
+        sig = sbox(fold(al, ah, kc.k0[j - 1]));
+        slo[j] = (u32)sig; shi[j] = (u32)(sig >> 32);
+    }
+    _Pragma("unroll") for (int r = 0; r < 12; r++) {
+        u64 al = 0, ah = 0;
+        _Pragma("unroll") for (int c = 0; c < 12; c++) { al += (u64)lo[c] * T.gK[r][c]; ah += (u64)hi[c] * T.gK[r][c]; }
+        _Pragma("unroll") for (int i = 0; i < K; i++) { al += (u64)slo[i] * T.bt[K - 1 - i][r]; ah += (u64)shi[i] * T.bt[K - 1 - i][r]; }
+        s[r] = fold(al, ah, kc.kK[r]);
+    }
+}
+static constexpr pblk::BlkConst<3> HPBM = pblk::make_blk<3, true>(4);
+static constexpr pblk::BlkConst<4> HPB4[4] = {pblk::make_blk<4, false>(7), pblk::make_blk<4, false>(11), pblk::make_blk<4, false>(15), pblk::make_blk<4, false>(19)};
+static constexpr pblk::BlkConst<3> HPB3 = pblk::make_blk<3, false>(23);
+}  // namespace host
+inline void permute(u64 s[12]) {                         // canonical in, canonical out
+    static const u64 ZERO12[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 12; i++) s[i] = add(s[i], RC[i]);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 12; i++) s[i] = host::sbox(s[i]);
+        if (r < 3) host::mds_add(s, RC + 12 * (r + 1));      // round 3's linear layer is inside the merged block
+    }
+    host::partial_block<3, true>(s, host::HPBM);             // rounds 4..6
+    for (int b = 0; b < 4; b++) host::partial_block<4, false>(s, host::HPB4[b]);     // rounds 7..22
+    host::partial_block<3, false>(s, host::HPB3);            // rounds 23..25
+    for (int r = 26; r < 30; r++) {
+        for (int i = 0; i < 12; i++) s[i] = host::sbox(s[i]);
+        host::mds_add(s, r < 29 ? RC + 12 * (r + 1) : ZERO12);
+    }
+    for (int i = 0; i < 12; i++) s[i] = canon(canon(s[i]));
+}
 inline u64 permute_coop(u64 x, int, int) { return x; }   // device-only; declared for the host parsing pass
 inline void permute_quad(u64 *, int) {}
 // device-only below; declared for the host parsing pass

@@ -369,6 +369,9 @@ GLP_API int glp_verify_n(const glp_circuit *circuit, const uint64_t *proof_words
  *   proofs       [K][glp_proof_words(circuit)], host memory
  *   status_out   [K]: GLP_OK = accepted, GLP_ERR_PROVE = rejected
  *   reasons_out  NULL, or [K][GLP_REASON_LEN] chars: the rejection reason of proof k (empty string if accepted)
+ * Under PoseidonGoldilocksConfig the K transcripts run on the device too (the batch prover's kernels over the uploaded proofs); the host keeps
+ * the canonical-form scan and the identity at zeta.  Environment variable GLP_VERIFY_HOST_TRANSCRIPT=1 (read per call): transcripts on host
+ * threads, as under KeccakGoldilocksConfig.
  * Returns GLP_OK when the batch was checked (whatever the verdicts), an error code for bad arguments / HIP failures. */
 #define GLP_REASON_LEN 160
 GLP_API int glp_verify_batch(glp_ctx *ctx, const glp_circuit *circuit, uint32_t num_proofs, const uint64_t *proofs, int32_t *status_out,

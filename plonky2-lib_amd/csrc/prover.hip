@@ -265,7 +265,6 @@ __device__ __forceinline__ u64 acc2_reduce(const AccLimb &a) {    // canonical
 // kernels -- what bounds how many gates share one pass over the wire planes -- for twice the (scalar) table loads.
 struct AccHL { u64 c0, c1, c2; };                         // c[j]: limb j of m (bits 22 j ..) times vlo + limb j of m' times vhi
 constexpr u32 ACC3_MAX_TERMS = 512;                       // 2 products < 2^54 per term and accumulator
-constexpr u32 APL_WORDS = 4;                              // table words per power: m0 | m1 << 32, m2, m0' | m1' << 32, m2'
 inline void apl_words(u64 m, u64 out[4]) {                // host side of the table
     const u64 mp = glf::mul(m, 1ull << 32);
     out[0] = (m & 0x3FFFFFull) | (((m >> 22) & 0x3FFFFFull) << 32); out[1] = m >> 44;

@@ -14,6 +14,7 @@ using namespace glf;
 
 constexpr int MAXCH = 4;      // num_challenges supported
 constexpr int MAXR = 16;      // 2^rate_bits supported
+constexpr u32 APL_WORDS = 4;  // table words per alpha power in the quotient kernels' limb form (prover.hip AccHL): m0 | m1 << 32, m2, m0' | m1' << 32, m2'
 
 struct DevGate { u32 type, selector_index, group_start, group_end, row, num_constraints, p0, p1; };
 

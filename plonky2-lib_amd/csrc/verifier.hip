@@ -14,6 +14,7 @@
 #include <thread>
 #include "merkle.h"
 #include "prover_types.h"
+#include "transcript_dev.h"
 
 namespace {
 
@@ -279,16 +280,12 @@ struct VChal {
     std::vector<E> fri_betas;
     std::vector<u64> x_index;
 };
-int verify_front(const glp_circuit *cc, const u64 *proof, VChal &vc) {
+#define FAIL(...) return set_error(GLP_ERR_PROVE, __VA_ARGS__)
+// field elements (and Poseidon digests) must be canonical; a KeccakHash<25> digest is 25 bytes in a 4-word slot
+int verify_canonical(const glp_circuit *cc, const u64 *proof) {
     const glp_circuit_desc &d = cc->d;
     const Layout &L = cc->L;
-    const int lg = (int)d.degree_bits, rb = (int)d.rate_bits, lgN = lg + rb;
-    const size_t n = (size_t)1 << lg, N = n << rb;
-    const u32 nch = d.num_challenges, nr = d.num_routed_wires, nw = d.num_wires, nc = d.num_constants;
-    const u32 qdf = d.quotient_degree_factor, npp = d.num_partial_products, capn = 1u << d.cap_height;
-    const u32 nchunks = npp + 1;
-#define FAIL(...) return set_error(GLP_ERR_PROVE, __VA_ARGS__)
-    {   // field elements (and Poseidon digests) must be canonical; a KeccakHash<25> digest is 25 bytes in a 4-word slot
+    {
         const bool kec25 = d.hasher == GLP_HASH_KECCAK25;
         const size_t dig_lo[2] = {0, L.fri_caps}, dig_hi[2] = {L.openings, L.queries};        // cap regions
         auto in_caps = [&](size_t i) { return (i >= dig_lo[0] && i < dig_hi[0]) || (i >= dig_lo[1] && i < dig_hi[1]); };
@@ -312,38 +309,21 @@ int verify_front(const glp_circuit *cc, const u64 *proof, VChal &vc) {
             if (proof[i] >= P) FAIL("proof word %zu is not a canonical field element", i);
         }
     }
+    return GLP_OK;
+}
+// vanishing(zeta) == Z_H(zeta) * reduce_with_powers(quotient chunks, zeta^n)     (plonk/verifier.rs), given the challenges
+int verify_vanishing(const glp_circuit *cc, const u64 *proof, const u64 *betas, const u64 *gammas, const u64 *alphas, const E &zeta, const u64 pih[4]);
 
-    // ---- transcript (plonk/get_challenges.rs)
-    u64 pih[4];
-    host_hash_no_pad(proof + L.pis, d.num_public_inputs, pih);
-    Challenger ch((int)d.hasher);
-    ch.observe_hashes(cc->digest, 1);
-    ch.observe(pih, 4);
-    ch.observe_hashes(proof + L.caps, capn);
-    u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
-    for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
-    for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
-    ch.observe_hashes(proof + L.caps + capn * 4, capn);
-    for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
-    ch.observe_hashes(proof + L.caps + 2 * capn * 4, capn);
-    const E zeta(ch.get_ext());
+int verify_vanishing(const glp_circuit *cc, const u64 *proof, const u64 *betas, const u64 *gammas, const u64 *alphas, const E &zeta, const u64 pih[4]) {
+    const glp_circuit_desc &d = cc->d;
+    const Layout &L = cc->L;
+    const int lg = (int)d.degree_bits;
+    const size_t n = (size_t)1 << lg;
+    const u32 nch = d.num_challenges, nr = d.num_routed_wires, nw = d.num_wires, nc = d.num_constants;
+    const u32 qdf = d.quotient_degree_factor, npp = d.num_partial_products, nchunks = npp + 1;
     const u64 *op = proof + L.openings;
     const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;
     const u64 *p_pp = p_zn + 2 * nch, *p_q = p_pp + 2 * nch * npp;
-    ch.observe(p_cs, 2 * (nc + nr)); ch.observe(p_w, 2 * nw); ch.observe(p_zs, 2 * nch);
-    ch.observe(p_pp, 2 * (size_t)nch * npp); ch.observe(p_q, 2 * (size_t)nch * qdf); ch.observe(p_zn, 2 * nch);
-    const E fri_alpha(ch.get_ext());
-    std::vector<E> fri_betas(d.num_reductions);
-    for (u32 r = 0; r < d.num_reductions; r++) {
-        ch.observe_hashes(proof + L.fri_caps + (size_t)r * capn * 4, capn);
-        fri_betas[r] = E(ch.get_ext());
-    }
-    ch.observe(proof + L.final_poly, 2 * (size_t)L.final_len);
-    ch.observe(proof + L.pow, 1);
-    const u64 pow_resp = ch.get();
-    if (d.proof_of_work_bits && (pow_resp >> (64 - d.proof_of_work_bits)) != 0) FAIL("Invalid proof of work witness.");
-
-    // ---- vanishing(zeta) == Z_H(zeta) * reduce_with_powers(quotient chunks, zeta^n)     (plonk/verifier.rs)
     {
         std::vector<E> lc(nc), sg(nr), lw(nw), zs(nch), zn(nch), pp((size_t)nch * npp);
         for (u32 k = 0; k < nc; k++) lc[k] = rd(p_cs + 2 * k);
@@ -389,6 +369,55 @@ int verify_front(const glp_circuit *cc, const u64 *proof, VChal &vc) {
             for (u32 k = qdf; k-- > 0;) t = t * zpow + rd(p_q + 2 * (i * qdf + k));
             if (!(van == zh * t)) FAIL("Mismatch between evaluation and opening of quotient polynomial (challenge %u)", i);
         }
+    }
+    return GLP_OK;
+}
+
+int verify_front(const glp_circuit *cc, const u64 *proof, VChal &vc) {
+    const glp_circuit_desc &d = cc->d;
+    const Layout &L = cc->L;
+    const int lg = (int)d.degree_bits, rb = (int)d.rate_bits, lgN = lg + rb;
+    const size_t n = (size_t)1 << lg, N = n << rb;
+    const u32 nch = d.num_challenges, nr = d.num_routed_wires, nw = d.num_wires, nc = d.num_constants;
+    const u32 qdf = d.quotient_degree_factor, npp = d.num_partial_products, capn = 1u << d.cap_height;
+    (void)n;
+    {
+        const int rc0 = verify_canonical(cc, proof);
+        if (rc0 != GLP_OK) return rc0;
+    }
+
+    // ---- transcript (plonk/get_challenges.rs)
+    u64 pih[4];
+    host_hash_no_pad(proof + L.pis, d.num_public_inputs, pih);
+    Challenger ch((int)d.hasher);
+    ch.observe_hashes(cc->digest, 1);
+    ch.observe(pih, 4);
+    ch.observe_hashes(proof + L.caps, capn);
+    u64 betas[MAXCH], gammas[MAXCH], alphas[MAXCH];
+    for (u32 i = 0; i < nch; i++) betas[i] = ch.get();
+    for (u32 i = 0; i < nch; i++) gammas[i] = ch.get();
+    ch.observe_hashes(proof + L.caps + capn * 4, capn);
+    for (u32 i = 0; i < nch; i++) alphas[i] = ch.get();
+    ch.observe_hashes(proof + L.caps + 2 * capn * 4, capn);
+    const E zeta(ch.get_ext());
+    const u64 *op = proof + L.openings;
+    const u64 *p_cs = op, *p_w = op + 2 * (nc + nr), *p_zs = p_w + 2 * nw, *p_zn = p_zs + 2 * nch;
+    const u64 *p_pp = p_zn + 2 * nch, *p_q = p_pp + 2 * nch * npp;
+    ch.observe(p_cs, 2 * (nc + nr)); ch.observe(p_w, 2 * nw); ch.observe(p_zs, 2 * nch);
+    ch.observe(p_pp, 2 * (size_t)nch * npp); ch.observe(p_q, 2 * (size_t)nch * qdf); ch.observe(p_zn, 2 * nch);
+    const E fri_alpha(ch.get_ext());
+    std::vector<E> fri_betas(d.num_reductions);
+    for (u32 r = 0; r < d.num_reductions; r++) {
+        ch.observe_hashes(proof + L.fri_caps + (size_t)r * capn * 4, capn);
+        fri_betas[r] = E(ch.get_ext());
+    }
+    ch.observe(proof + L.final_poly, 2 * (size_t)L.final_len);
+    ch.observe(proof + L.pow, 1);
+    const u64 pow_resp = ch.get();
+    if (d.proof_of_work_bits && (pow_resp >> (64 - d.proof_of_work_bits)) != 0) FAIL("Invalid proof of work witness.");
+    {
+        const int rcv = verify_vanishing(cc, proof, betas, gammas, alphas, zeta, pih);
+        if (rcv != GLP_OK) return rcv;
     }
 
     // ---- FRI (fri/verifier.rs): reduced openings and query indices
@@ -705,24 +734,93 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
         up_err = hipSetDevice(c->device);
         if (up_err == hipSuccess) up_err = hipMemcpyAsync(dev_proofs, proofs, (size_t)K * L.total * 8, hipMemcpyHostToDevice, c->stream);
     });
-    // host half, one proof per task on the context's pool: canonical form, transcript, proof of work, vanishing polynomial at zeta
-    ctx_host_pool(c).run(K, [&](size_t k) {
-        rc[k] = verify_front(cc, proofs + k * L.total, vcs[k]);
-        if (rc[k] != GLP_OK) { why[k] = g_last_error; return; }
-        const VChal &v = vcs[k];
-        u64 *o = &hv[k * vstride];
-        auto put = [&](u32 at, const E &e) { o[at] = e.v.a; o[at + 1] = e.v.b; };
-        put(VC_ALPHA, v.fri_alpha); put(VC_ZETA, v.zeta); put(VC_ZETA_NEXT, v.zeta_next); put(VC_RED0, v.red0); put(VC_RED1, v.red1); put(VC_SHIFT1, v.shift1);
-        for (u32 r = 0; r < nred; r++) put(VC_BETAS + 2 * r, v.fri_betas[r]);
-        for (u32 q = 0; q < nq; q++) o[VC_XIDX + q] = v.x_index[q];
-    });
-    // device half: every query round of every proof in one launch.  Proofs the host half already rejected still ride along
-    // (their slots hold zero challenges and every index is in range); their device status is ignored.
-    const double t_front = since();
-    uploader.join();
-    const double t_up = since();
-    if (up_err != hipSuccess) return set_error(GLP_ERR_HIP, "upload of the proofs: %s", hipGetErrorString(up_err));
-    GLP_HIP(hipMemcpyAsync(dev_vc, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
+    // PoseidonGoldilocksConfig: the K transcripts run on the device, as the batch prover's do (transcript_dev.h; the uploaded proofs are
+    // the image its kernels read).  The host keeps the canonical-form scan (beside the upload) and the vanishing-polynomial identity
+    // (beside the query rounds).  KeccakGoldilocksConfig, or GLP_VERIFY_HOST_TRANSCRIPT=1: everything of verify_front on host threads.
+    const bool dev_tr = d.hasher == GLP_HASH_POSEIDON && getenv("GLP_VERIFY_HOST_TRANSCRIPT") == nullptr;
+    const u32 nch = d.num_challenges, capn = 1u << d.cap_height;
+    u64 *dev_chal = nullptr, *dev_qpp = nullptr, *dev_apow = nullptr, *dev_zetas = nullptr;
+    u32 *dev_err = nullptr;
+    std::vector<u64> h_chal, h_qpp, h_apow, h_zetas;
+    std::vector<u32> h_err;
+    hipEvent_t ev_chal = nullptr;
+    struct EvGuard { hipEvent_t &e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evg{ev_chal};
+    double t_front = 0, t_up = 0;
+    if (!dev_tr) {
+        // host half, one proof per task on the context's pool: canonical form, transcript, proof of work, vanishing polynomial at zeta
+        ctx_host_pool(c).run(K, [&](size_t k) {
+            rc[k] = verify_front(cc, proofs + k * L.total, vcs[k]);
+            if (rc[k] != GLP_OK) { why[k] = g_last_error; return; }
+            const VChal &v = vcs[k];
+            u64 *o = &hv[k * vstride];
+            auto put = [&](u32 at, const E &e) { o[at] = e.v.a; o[at + 1] = e.v.b; };
+            put(VC_ALPHA, v.fri_alpha); put(VC_ZETA, v.zeta); put(VC_ZETA_NEXT, v.zeta_next); put(VC_RED0, v.red0); put(VC_RED1, v.red1); put(VC_SHIFT1, v.shift1);
+            for (u32 r = 0; r < nred; r++) put(VC_BETAS + 2 * r, v.fri_betas[r]);
+            for (u32 q = 0; q < nq; q++) o[VC_XIDX + q] = v.x_index[q];
+        });
+        // device half: every query round of every proof in one launch.  Proofs the host half already rejected still ride along
+        // (their slots hold zero challenges and every index is in range); their device status is ignored.
+        t_front = since();
+        uploader.join();
+        t_up = since();
+        if (up_err != hipSuccess) return set_error(GLP_ERR_HIP, "upload of the proofs: %s", hipGetErrorString(up_err));
+        GLP_HIP(hipMemcpyAsync(dev_vc, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, c->stream));
+    } else {
+        ctx_host_pool(c).run(K, [&](size_t k) {
+            rc[k] = verify_canonical(cc, proofs + k * L.total);
+            if (rc[k] != GLP_OK) why[k] = g_last_error;
+        });
+        t_front = since();
+        uploader.join();
+        t_up = since();
+        if (up_err != hipSuccess) return set_error(GLP_ERR_HIP, "upload of the proofs: %s", hipGetErrorString(up_err));
+        const u32 total_cols = L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3];
+        u64 *dch, *dev_apl, *dev_fap, *dev_fpp, *dev_betas, *dev_idx;
+        GLP_TRY(get((void **)&dch, (size_t)K * DCH_WORDS * 8));
+        GLP_TRY(get((void **)&dev_chal, (size_t)K * 2 * MAXCH * 8));
+        GLP_TRY(get((void **)&dev_qpp, (size_t)K * 3 * MAXCH * 8));
+        GLP_TRY(get((void **)&dev_apow, (size_t)K * nch * 2 * 8));
+        GLP_TRY(get((void **)&dev_apl, (size_t)K * nch * 2 * APL_WORDS * 8));
+        GLP_TRY(get((void **)&dev_zetas, (size_t)K * 4 * 8));
+        GLP_TRY(get((void **)&dev_fap, (size_t)K * 2 * total_cols * 8));
+        GLP_TRY(get((void **)&dev_fpp, (size_t)K * 10 * 8));
+        GLP_TRY(get((void **)&dev_betas, (size_t)std::max<u32>(nred, 1) * K * 2 * 8));
+        GLP_TRY(get((void **)&dev_idx, (size_t)K * nq * 8));
+        GLP_TRY(get((void **)&dev_err, (size_t)K * 4));
+        GLP_HIP(hipMemsetAsync(dev_chal, 0, (size_t)K * 2 * MAXCH * 8, c->stream));
+        GLP_HIP(hipMemsetAsync(dev_qpp, 0, (size_t)K * 3 * MAXCH * 8, c->stream));
+        GLP_HIP(hipMemsetAsync(dev_err, 0, (size_t)K * 4, c->stream));
+        TrGeo g;
+        g.dch = dch; g.image = dev_proofs; g.total = L.total; g.K = K; g.capn = capn; g.nch = nch;
+        const dim3 tg((K + 15) / 16), tb(256);
+        const size_t cap4 = (size_t)capn * 4;
+        // a cap is "copied" from the image onto itself: source = image + offset with the proof stride, destination offset the same
+        hipLaunchKernelGGL(k_tr_begin, tg, tb, 0, c->stream, g, cc->digest[0], cc->digest[1], cc->digest[2], cc->digest[3], L.pis, d.num_public_inputs,
+                           dev_proofs + L.caps, L.total, L.caps, dev_chal, dev_qpp);
+        hipLaunchKernelGGL(k_tr_alphas, tg, tb, 0, c->stream, g, dev_proofs + L.caps + cap4, L.total, L.caps + cap4, 2u, dev_apow, dev_apl);
+        hipLaunchKernelGGL(k_tr_zeta, tg, tb, 0, c->stream, g, dev_proofs + L.caps + 2 * cap4, L.total, L.caps + 2 * cap4, d.degree_bits,
+                           root_of_unity((int)d.degree_bits), dev_zetas, dev_err);
+        OpenGeo og;
+        memset(&og, 0, sizeof(og));
+        for (int b = 0; b < 4; b++) og.cols[b] = L.oracle_cols[b];
+        og.openings_off = L.openings; og.nch = nch; og.npp = d.num_partial_products; og.nopen = (u32)L.nopen;
+        hipLaunchKernelGGL(k_tr_fri_alpha, tg, tb, 0, c->stream, g, og, dev_zetas, dev_fap, dev_fpp);
+        for (u32 r = 0; r < nred; r++)
+            hipLaunchKernelGGL(k_tr_beta, tg, tb, 0, c->stream, g, dev_proofs + L.fri_caps + r * cap4, L.total, L.fri_caps + r * cap4, dev_betas + (size_t)r * K * 2);
+        hipLaunchKernelGGL(k_trv_final, tg, tb, 0, c->stream, g, L.final_poly, 2u * L.final_len);
+        hipLaunchKernelGGL(k_trv_queries, tg, tb, 0, c->stream, g, d.proof_of_work_bits, L.pow, nq, (u64)1 << (d.degree_bits + d.rate_bits), dev_idx, dev_err);
+        hipLaunchKernelGGL(k_trv_pack, dim3((K + 255) / 256), dim3(256), 0, c->stream, K, vstride, dev_fap, total_cols, dev_fpp, dev_betas, nred, dev_idx, nq, dev_vc);
+        GLP_HIP(hipGetLastError());
+        // what the host's half of the check needs comes back while the query rounds run
+        h_chal.resize((size_t)K * 2 * MAXCH); h_qpp.resize((size_t)K * 3 * MAXCH); h_apow.resize((size_t)K * nch * 2); h_zetas.resize((size_t)K * 4); h_err.resize(K);
+        GLP_HIP(hipMemcpyAsync(h_chal.data(), dev_chal, h_chal.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        GLP_HIP(hipMemcpyAsync(h_qpp.data(), dev_qpp, h_qpp.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        GLP_HIP(hipMemcpyAsync(h_apow.data(), dev_apow, h_apow.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        GLP_HIP(hipMemcpyAsync(h_zetas.data(), dev_zetas, h_zetas.size() * 8, hipMemcpyDeviceToHost, c->stream));
+        GLP_HIP(hipMemcpyAsync(h_err.data(), dev_err, h_err.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        GLP_HIP(hipEventCreateWithFlags(&ev_chal, hipEventDisableTiming));
+        GLP_HIP(hipEventRecord(ev_chal, c->stream));
+    }
     VQArgs a;
     memset(&a, 0, sizeof(a));
     a.proofs = dev_proofs; a.vchal = dev_vc; a.status = dev_status;
@@ -743,8 +841,28 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     }
     std::vector<u32> hs((size_t)K * nq);
     GLP_HIP(hipMemcpyAsync(hs.data(), dev_status, hs.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    double t_chal = 0, t_van = 0;
+    if (dev_tr) {
+        GLP_HIP(hipEventSynchronize(ev_chal));
+        t_chal = since();
+        // same order of checks as verify_front: canonical form (above), proof of work, then the identity at zeta
+        ctx_host_pool(c).run(K, [&](size_t k) {
+            if (rc[k] != GLP_OK) return;
+            if (h_err[k] & 8u) { rc[k] = set_error(GLP_ERR_PROVE, "Invalid proof of work witness."); why[k] = g_last_error; return; }
+            u64 alphas[MAXCH] = {0, 0, 0, 0};
+            for (u32 i = 0; i < nch; i++) alphas[i] = h_apow[(k * nch + i) * 2 + 1];
+            const E zeta(e_make(h_zetas[4 * k], h_zetas[4 * k + 1]));
+            rc[k] = verify_vanishing(cc, proofs + k * L.total, &h_chal[k * 2 * MAXCH], &h_chal[k * 2 * MAXCH + MAXCH], alphas, zeta, &h_qpp[k * 3 * MAXCH + 2 * MAXCH]);
+            if (rc[k] != GLP_OK) why[k] = g_last_error;
+        });
+        t_van = since();
+    }
     GLP_HIP(hipStreamSynchronize(c->stream));
-    if (trace) fprintf(stderr, "[glp_verify_batch K=%u] host half %.3f ms | upload done at %.3f | query rounds done at %.3f ms\n", K, t_front, t_up, since());
+    if (trace) {
+        if (dev_tr) fprintf(stderr, "[glp_verify_batch K=%u dev] canonical scan %.3f ms | upload done at %.3f | challenges back at %.3f | identity at zeta done at %.3f | query rounds done at %.3f ms\n",
+                            K, t_front, t_up, t_chal, t_van, since());
+        else fprintf(stderr, "[glp_verify_batch K=%u] host half %.3f ms | upload done at %.3f | query rounds done at %.3f ms\n", K, t_front, t_up, since());
+    }
     for (u32 k = 0; k < K; k++) {
         if (rc[k] == GLP_OK)
             for (u32 q = 0; q < nq && rc[k] == GLP_OK; q++)

@@ -99,6 +99,24 @@ def test_verdicts_and_reasons_equal_the_host_verifier(ctx, oracle, which):
     gc.free()
 
 
+def test_host_and_device_transcripts_of_the_verifier_agree(ctx):
+    """PoseidonGoldilocksConfig runs the K transcripts on the device (the prover's kernels over the uploaded proofs); GLP_VERIFY_HOST_TRANSCRIPT=1
+    keeps them on host threads (what KeccakGoldilocksConfig always does): same verdicts, same reasons, on a batch tampered section by section."""
+    import os
+    desc = synth.smt_shape_circuit(10, seed=9)
+    gc = glp.Circuit(ctx, desc)
+    names, batch = _tampered_batch(gc.prove(), desc, np.random.default_rng(23))
+    dev_ok, dev_why = gc.verify_batch(batch, reasons=True)
+    os.environ["GLP_VERIFY_HOST_TRANSCRIPT"] = "1"
+    try:
+        host_ok, host_why = gc.verify_batch(batch, reasons=True)
+    finally:
+        del os.environ["GLP_VERIFY_HOST_TRANSCRIPT"]
+    assert list(dev_ok) == list(host_ok) and list(dev_why) == list(host_why), list(zip(names, dev_why, host_why))
+    assert dev_ok[0] and dev_ok[-1] and dev_ok.sum() == 2
+    gc.free()
+
+
 def test_keccak_config_batch(ctx, oracle):
     """KeccakGoldilocksConfig: KeccakHash<25> paths and caps on the device side of the verifier"""
     desc = synth.zkdsa_circuit(3)

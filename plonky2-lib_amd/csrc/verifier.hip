@@ -741,8 +741,9 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
     const u32 nch = d.num_challenges, capn = 1u << d.cap_height;
     u64 *dev_chal = nullptr, *dev_qpp = nullptr, *dev_apow = nullptr, *dev_zetas = nullptr;
     u32 *dev_err = nullptr;
-    std::vector<u64> h_chal, h_qpp, h_apow, h_zetas;
-    std::vector<u32> h_err;
+    std::vector<u64> h_back;
+    const u64 *h_chal = nullptr, *h_qpp = nullptr, *h_apow = nullptr, *h_zetas = nullptr;
+    const u32 *h_err = nullptr;
     hipEvent_t ev_chal = nullptr;
     struct EvGuard { hipEvent_t &e; ~EvGuard() { if (e) (void)hipEventDestroy(e); } } evg{ev_chal};
     double t_front = 0, t_up = 0;
@@ -777,19 +778,17 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
         const u32 total_cols = L.oracle_cols[0] + L.oracle_cols[1] + L.oracle_cols[2] + L.oracle_cols[3];
         u64 *dch, *dev_apl, *dev_fap, *dev_fpp, *dev_betas, *dev_idx;
         GLP_TRY(get((void **)&dch, (size_t)K * DCH_WORDS * 8));
-        GLP_TRY(get((void **)&dev_chal, (size_t)K * 2 * MAXCH * 8));
-        GLP_TRY(get((void **)&dev_qpp, (size_t)K * 3 * MAXCH * 8));
-        GLP_TRY(get((void **)&dev_apow, (size_t)K * nch * 2 * 8));
+        // betas | gammas, public-input hash, alpha powers, zetas, error bits: one block, one copy back
+        const size_t w_chal = (size_t)K * 2 * MAXCH, w_qpp = (size_t)K * 3 * MAXCH, w_apow = (size_t)K * nch * 2, w_zetas = (size_t)K * 4, w_err = (K + 1) / 2;
+        u64 *dev_back;
+        GLP_TRY(get((void **)&dev_back, (w_chal + w_qpp + w_apow + w_zetas + w_err) * 8));
+        dev_chal = dev_back; dev_qpp = dev_chal + w_chal; dev_apow = dev_qpp + w_qpp; dev_zetas = dev_apow + w_apow; dev_err = (u32 *)(dev_zetas + w_zetas);
         GLP_TRY(get((void **)&dev_apl, (size_t)K * nch * 2 * APL_WORDS * 8));
-        GLP_TRY(get((void **)&dev_zetas, (size_t)K * 4 * 8));
         GLP_TRY(get((void **)&dev_fap, (size_t)K * 2 * total_cols * 8));
         GLP_TRY(get((void **)&dev_fpp, (size_t)K * 10 * 8));
         GLP_TRY(get((void **)&dev_betas, (size_t)std::max<u32>(nred, 1) * K * 2 * 8));
         GLP_TRY(get((void **)&dev_idx, (size_t)K * nq * 8));
-        GLP_TRY(get((void **)&dev_err, (size_t)K * 4));
-        GLP_HIP(hipMemsetAsync(dev_chal, 0, (size_t)K * 2 * MAXCH * 8, c->stream));
-        GLP_HIP(hipMemsetAsync(dev_qpp, 0, (size_t)K * 3 * MAXCH * 8, c->stream));
-        GLP_HIP(hipMemsetAsync(dev_err, 0, (size_t)K * 4, c->stream));
+        GLP_HIP(hipMemsetAsync(dev_back, 0, (w_chal + w_qpp + w_apow + w_zetas + w_err) * 8, c->stream));
         TrGeo g;
         g.dch = dch; g.image = dev_proofs; g.total = L.total; g.K = K; g.capn = capn; g.nch = nch;
         const dim3 tg((K + 15) / 16), tb(256);
@@ -812,14 +811,11 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
         hipLaunchKernelGGL(k_trv_pack, dim3((K + 255) / 256), dim3(256), 0, c->stream, K, vstride, dev_fap, total_cols, dev_fpp, dev_betas, nred, dev_idx, nq, dev_vc);
         GLP_HIP(hipGetLastError());
         // what the host's half of the check needs comes back while the query rounds run
-        h_chal.resize((size_t)K * 2 * MAXCH); h_qpp.resize((size_t)K * 3 * MAXCH); h_apow.resize((size_t)K * nch * 2); h_zetas.resize((size_t)K * 4); h_err.resize(K);
-        GLP_HIP(hipMemcpyAsync(h_chal.data(), dev_chal, h_chal.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        GLP_HIP(hipMemcpyAsync(h_qpp.data(), dev_qpp, h_qpp.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        GLP_HIP(hipMemcpyAsync(h_apow.data(), dev_apow, h_apow.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        GLP_HIP(hipMemcpyAsync(h_zetas.data(), dev_zetas, h_zetas.size() * 8, hipMemcpyDeviceToHost, c->stream));
-        GLP_HIP(hipMemcpyAsync(h_err.data(), dev_err, h_err.size() * 4, hipMemcpyDeviceToHost, c->stream));
+        h_back.resize(w_chal + w_qpp + w_apow + w_zetas + w_err);
+        GLP_HIP(hipMemcpyAsync(h_back.data(), dev_back, h_back.size() * 8, hipMemcpyDeviceToHost, c->stream));
         GLP_HIP(hipEventCreateWithFlags(&ev_chal, hipEventDisableTiming));
         GLP_HIP(hipEventRecord(ev_chal, c->stream));
+        h_chal = h_back.data(); h_qpp = h_chal + w_chal; h_apow = h_qpp + w_qpp; h_zetas = h_apow + w_apow; h_err = (const u32 *)(h_zetas + w_zetas);
     }
     VQArgs a;
     memset(&a, 0, sizeof(a));
@@ -840,7 +836,6 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
         GLP_HIP(hipGetLastError());
     }
     std::vector<u32> hs((size_t)K * nq);
-    GLP_HIP(hipMemcpyAsync(hs.data(), dev_status, hs.size() * 4, hipMemcpyDeviceToHost, c->stream));
     double t_chal = 0, t_van = 0;
     if (dev_tr) {
         GLP_HIP(hipEventSynchronize(ev_chal));
@@ -857,6 +852,8 @@ extern "C" int glp_verify_batch(glp_ctx *c, const glp_circuit *cc, uint32_t K, c
         });
         t_van = since();
     }
+    // (a copy into pageable memory blocks its caller until the stream gets there: enqueued only now, the identity at zeta ran beside the query rounds)
+    GLP_HIP(hipMemcpyAsync(hs.data(), dev_status, hs.size() * 4, hipMemcpyDeviceToHost, c->stream));
     GLP_HIP(hipStreamSynchronize(c->stream));
     if (trace) {
         if (dev_tr) fprintf(stderr, "[glp_verify_batch K=%u dev] canonical scan %.3f ms | upload done at %.3f | challenges back at %.3f | identity at zeta done at %.3f | query rounds done at %.3f ms\n",

@@ -120,6 +120,51 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
         }
     }
 }
+
+// The same for traces of at most 64 rows (a batch of small proofs: blockIdx.y = proof, one workgroup per proof).  k_pp_rows gives a row to a lane, and a
+// lane then walks ~1000 dependent multiplications (80 wires x two challenges, one inversion per challenge) while 56 lanes of its wave idle: 120 us per 256
+// zkdsa proofs, all of it latency.  Here a lane takes one (row, chunk, challenge): the chunk products in parallel through LDS, then one lane per
+// (row, challenge) for the prefix products, the inversion and the walk back -- ~170 dependent multiplications.  Same values in the same places.
+__global__ __launch_bounds__(256) void k_pp_rows_small(PPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 pp_lds[];
+    const u32 n = 1u << a.lg, nchunks = a.npp + 1, nch = a.nch, units = n * nchunks * nch;
+    u64 *snum = pp_lds, *sden = pp_lds + units;              // [c][chunk][i]
+    const size_t pk = blockIdx.y;
+    if (a.chal) { a.wires += pk * a.wires_stride; a.zp += pk * a.zp_stride; }
+    const u64 *ch = a.chal ? a.chal + pk * 2 * MAXCH : nullptr;
+    for (u32 u = threadIdx.x; u < units; u += 256) {
+        const u32 i = u % n, chunk = (u / n) % nchunks, c = u / (n * nchunks);
+        const u64 beta = ch ? ch[c] : a.betas[c], gamma = ch ? ch[MAXCH + c] : a.gammas[c];
+        const u64 x = dpow(a.w_n, i);
+        u64 num = 1, den = 1;
+        const u32 j1 = min((chunk + 1) * a.qdf, a.nr);
+        for (u32 j = chunk * a.qdf; j < j1; j++) {
+            const u64 w = a.wires[(size_t)j * n + i], sg = a.sigmas[(size_t)j * n + i];
+            num = mul(num, add(add(w, mul(beta, mul(a.k_is[j], x))), gamma));
+            den = mul(den, add(add(w, mul(beta, sg)), gamma));
+        }
+        snum[u] = num; sden[u] = den;
+    }
+    __syncthreads();
+    for (u32 u = threadIdx.x; u < n * nch; u += 256) {
+        const u32 i = u % n, c = u / n;
+        const u64 *nm = snum + (size_t)c * nchunks * n + i, *dn = sden + (size_t)c * nchunks * n + i;
+        u64 pn = 1, pd = 1;
+        for (u32 chunk = 0; chunk < nchunks; chunk++) {
+            pn = mul(pn, nm[(size_t)chunk * n]);
+            pd = mul(pd, dn[(size_t)chunk * n]);
+            const u32 col = chunk < a.npp ? nch + c * a.npp + chunk : c;   // Z column holds the row product for now
+            a.zp[(size_t)col * n + i] = pn;
+        }
+        u64 ipd = inv(pd);
+        for (int chunk = (int)a.npp; chunk >= 0; chunk--) {
+            const u32 col = (u32)chunk < a.npp ? nch + c * a.npp + chunk : c;
+            const size_t o = (size_t)col * n + i;
+            a.zp[o] = mul(a.zp[o], ipd);
+            ipd = mul(ipd, dn[(size_t)chunk * n]);
+        }
+    }
+}
 // K5b: product of each block of 256 row products
 __global__ __launch_bounds__(256) void k_pp_block_tot(const u64 *zp, u64 *tot, u32 lg, u32 nblocks, size_t zp_stride) {
     __shared__ u64 sh[256];
@@ -1030,6 +1075,53 @@ __global__ __launch_bounds__(256) void k_final_values(FVArgs a) {
     ext2 f = e_mul(e_mul(e_sub(acc0, a.red0), d0), a.shift_acc);
     f = e_add(f, e_mul(e_sub(acc1, a.red1), d1));
     a.out[q] = f.a; a.out[n + q] = f.b;
+}
+
+// The same for at most 64 points per proof (a batch of small proofs: blockIdx.y = proof, one workgroup per proof): 256 / n lanes share a point, each
+// takes every (256 / n)-th column of the four oracles, an xor-butterfly adds the partial sums up, and lanes 0 and 1 of the group invert the two
+// denominators side by side.  k_final_values walks ~250 columns and two extension inversions per lane with 8 lanes live: 105 us per 256 zkdsa proofs.
+__global__ __launch_bounds__(256) void k_final_values_small(FVArgs a) {
+    const u32 n = 1u << a.lg, lpp = 256u >> a.lg;            // lanes per point: 4 .. 256
+    const size_t N = (size_t)n << a.rb;
+    const u32 q = threadIdx.x / lpp, t = threadIdx.x % lpp;
+    {
+        const size_t pk = blockIdx.y;
+        const u64 *v = a.pp + pk * 10;
+        a.red0 = e_make(v[0], v[1]); a.red1 = e_make(v[2], v[3]); a.zeta = e_make(v[4], v[5]); a.zeta_next = e_make(v[6], v[7]);
+        a.shift_acc = e_make(v[8], v[9]);
+        _Pragma("unroll") for (int k = 0; k < 4; k++) a.lde[k] += pk * a.lde_stride[k];
+        a.apow += pk * a.apow_stride; a.out += pk * a.out_stride;
+    }
+    ext2 acc0 = e_from(0), acc1 = e_from(0);
+    AccLimb xa, xb;
+    acc2_zero(xa); acc2_zero(xb);
+    u32 base = 0;
+    for (int k = 0; k < 4; k++) {
+        const u64 *l = a.lde[k] + q;
+        for (u32 c = t; c < a.ncols[k]; c += lpp) {          // fewer than ACC_MAX_TERMS terms per lane: no flush
+            const u32 j = base + c;
+            const u64 v = l[(size_t)c * N];
+            const u32 v0 = (u32)v & 0x3FFFFFu, v1 = (u32)(v >> 22) & 0x3FFFFFu, v2 = (u32)(v >> 44);
+            acc2_fma(xa, v0, v1, v2, a.apow[2 * j]);
+            acc2_fma(xb, v0, v1, v2, a.apow[2 * j + 1]);
+            if (k == 2 && c < a.nch) acc1 = e_add(acc1, e_scale(e_make(a.apow[2 * c], a.apow[2 * c + 1]), v));
+        }
+        base += a.ncols[k];
+    }
+    acc0 = e_make(acc2_reduce(xa), acc2_reduce(xb));
+    for (u32 m = lpp >> 1; m >= 1; m >>= 1) {                // lpp <= 64 here (n >= 4): the group lies inside one wavefront
+        acc0 = e_add(acc0, e_make(pos::shfl_xor64(acc0.a, (int)m), pos::shfl_xor64(acc0.b, (int)m)));
+        acc1 = e_add(acc1, e_make(pos::shfl_xor64(acc1.a, (int)m), pos::shfl_xor64(acc1.b, (int)m)));
+    }
+    const u64 x = mul(a.g, dpow(a.w_n, q));
+    const ext2 dmine = e_inv(e_sub(e_from(x), t == 1 ? a.zeta_next : a.zeta));       // lane 0: 1 / (x - zeta), lane 1: 1 / (x - zeta_next)
+    const int lane1 = (int)((threadIdx.x & 63u) - t + 1);
+    const ext2 d1 = e_make(pos::shfl64(dmine.a, lane1), pos::shfl64(dmine.b, lane1));
+    if (t == 0) {
+        ext2 f = e_mul(e_mul(e_sub(acc0, a.red0), dmine), a.shift_acc);
+        f = e_add(f, e_mul(e_sub(acc1, a.red1), d1));
+        a.out[q] = f.a; a.out[n + q] = f.b;
+    }
 }
 // data[c][p] *= base^bitrev(p)
 __global__ __launch_bounds__(256) void k_scale_bitrev_pow(u64 *data, u64 base, u32 lg) {

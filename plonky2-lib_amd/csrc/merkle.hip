@@ -182,6 +182,23 @@ __global__ __launch_bounds__(256) void k_merkle_level_coop(const u64 *__restrict
     if (live && l < 4) out[4 * i + l] = x;
 }
 
+// Levels between the two (merkle_quad_max >= parents > MERKLE_COOP_MAX_PARENTS): one parent per quad of lanes (pos::permute_quad)
+__global__ __launch_bounds__(256) void k_merkle_level_quad(const u64 *__restrict__ in, u64 *__restrict__ out, size_t m, size_t dig_stride) {
+    in += (size_t)blockIdx.y * dig_stride; out += (size_t)blockIdx.y * dig_stride;
+    const int tid = threadIdx.x, q = tid & 3;
+    const size_t i0 = (size_t)blockIdx.x * 64 + (tid >> 2);
+    const bool live = i0 < m;
+    const size_t i = live ? i0 : 0;
+    u64 x[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) x[s] = 3 * q + s < 8 ? in[8 * i + 3 * q + s] : 0;
+    pos::permute_quad(x, q);
+    if (live) {
+        if (q == 0) { out[4 * i] = x[0]; out[4 * i + 1] = x[1]; out[4 * i + 2] = x[2]; }
+        if (q == 1) out[4 * i + 3] = x[0];
+    }
+}
+
 __global__ void k_permute_states(u64 *states, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -247,6 +264,8 @@ static int build_levels(glp_ctx *c, u64 *dev_digests, size_t nleaves, int cap_he
             hipLaunchKernelGGL(k_merkle_level_keccak, dim3((unsigned)((m + 255) / 256), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
         else if (m * K <= MERKLE_COOP_MAX_PARENTS)   // few hashes: 12 lanes per hash for latency
             hipLaunchKernelGGL(k_merkle_level_coop, dim3((unsigned)((m + 15) / 16), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
+        else if (m * K <= c->merkle_quad_max)
+            hipLaunchKernelGGL(k_merkle_level_quad, dim3((unsigned)((m + 63) / 64), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
         else
             hipLaunchKernelGGL(k_merkle_level, dim3((unsigned)((m + 255) / 256), K), dim3(256), 0, c->stream, lvl, nxt, m, dig_stride);
         GLP_HIP(hipGetLastError());

@@ -1184,6 +1184,36 @@ __global__ __launch_bounds__(256) void k_fri_leaf_hash_coop(const u64 *vals, u64
     if (live && l < 4) digests[4 * m + l] = x;
 }
 // K9a with KeccakHash<25>: hash_or_noop of the leaf's 2^(ab+1) elements (arity 2 already exceeds the 3 elements that are copied)
+// one leaf per quad of lanes (pos::permute_quad): layers of 2^12..2^15 leaves, as for the initial trees (merkle.hip)
+__global__ __launch_bounds__(256) void k_fri_leaf_hash_quad(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab, size_t vals_bstride,
+                                                            size_t dig_bstride) {
+    vals += (size_t)blockIdx.y * vals_bstride; digests += (size_t)blockIdx.y * dig_bstride;
+    const size_t L = (size_t)1 << lgL, ncur = L >> rb, nleaves = L >> ab;
+    const int tid = threadIdx.x, q = tid & 3;
+    const size_t Mp0 = (size_t)blockIdx.x * 64 + (tid >> 2);
+    const bool live = Mp0 < nleaves;
+    const size_t Mp = live ? Mp0 : 0;
+    const size_t m = bitrev32((u32)Mp, lgL - ab);
+    const u32 len = 2u << ab;                       // base-field elements per leaf
+    u64 x[3] = {0, 0, 0};
+    for (u32 c = 0; c < len; c += 8) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            const u32 e8 = 3 * q + s, e = c + e8;
+            if (e8 < 8 && e < len) {
+                const u32 t = e >> 1;
+                const size_t i = (size_t)bitrev32(t, ab) * nleaves + Mp;
+                const size_t pos = (i & (((size_t)1 << rb) - 1)) * ncur + (i >> rb);
+                x[s] = vals[(e & 1 ? L : 0) + pos];
+            }
+        }
+        if (len > 4) pos::permute_quad(x, q);
+    }
+    if (live) {
+        if (q == 0) { digests[4 * m] = x[0]; digests[4 * m + 1] = x[1]; digests[4 * m + 2] = x[2]; }
+        if (q == 1) digests[4 * m + 3] = x[0];
+    }
+}
 __global__ __launch_bounds__(256) void k_fri_leaf_hash_keccak(const u64 *vals, u64 *digests, u32 lgL, u32 rb, u32 ab, size_t vals_bstride,
                                                               size_t dig_bstride) {
     vals += (size_t)blockIdx.y * vals_bstride; digests += (size_t)blockIdx.y * dig_bstride;
@@ -1756,8 +1786,11 @@ struct glp_session {
         if (hasher == GLP_HASH_KECCAK25)
             hipLaunchKernelGGL(k_fri_leaf_hash_keccak, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab, (size_t)0,
                                (size_t)0);
-        else if (nleaves <= 8192)
+        else if (nleaves <= c->merkle_coop_max)
             hipLaunchKernelGGL(k_fri_leaf_hash_coop, dim3((unsigned)((nleaves + 15) / 16)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
+                               (u32)rb, ab, (size_t)0, (size_t)0);
+        else if (nleaves <= c->merkle_quad_max)
+            hipLaunchKernelGGL(k_fri_leaf_hash_quad, dim3((unsigned)((nleaves + 63) / 64)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL,
                                (u32)rb, ab, (size_t)0, (size_t)0);
         else
             hipLaunchKernelGGL(k_fri_leaf_hash, dim3(nblk(nleaves)), dim3(256), 0, c->stream, ly.vals, ly.dig, lgL, (u32)rb, ab, (size_t)0,

@@ -56,6 +56,7 @@ GLP_API int glp_device_count(void);
  *   GLP_NTT_STRIDED32_TL  = 1..64  (default 8):  tiles one block of that kernel walks, software-pipelined (1 = one tile per block)
  *   GLP_MERKLE_COOP_MAX   (default 4096), GLP_MERKLE_QUAD_MAX (default 32768): Poseidon leaf hashing spreads one sponge over 12 of 16 lanes up to
  *                         the first many leaves per launch, over a quad of lanes up to the second, and keeps one sponge per lane above it
+ *                         (FRI layers alike; Merkle levels: 12 of 16 lanes up to 8192 parents, a quad up to the second threshold)
  *   GLP_HOST_THREADS      (read on the first glp_prove_batch of a context): host threads for the transcripts of a batch */
 GLP_API int glp_ctx_create(int device_id, glp_ctx **out);
 GLP_API void glp_ctx_destroy(glp_ctx *ctx);

@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(256) void k_final_values_small(FVArgs a) {
     const u32 n = 1u << a.lg, lpp = 256u >> a.lg;            // lanes per point: 4 .. 256
     const size_t N = (size_t)n << a.rb;
     const u32 q = threadIdx.x / lpp, t = threadIdx.x % lpp;
-    {
+    if (a.pp) {
         const size_t pk = blockIdx.y;
         const u64 *v = a.pp + pk * 10;
         a.red0 = e_make(v[0], v[1]); a.red1 = e_make(v[2], v[3]); a.zeta = e_make(v[4], v[5]); a.zeta_next = e_make(v[6], v[7]);
@@ -1554,7 +1554,9 @@ struct glp_session {
             for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
             a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
             a.chal = nullptr; a.wires_stride = 0; a.zp_stride = 0;
-            switch (nch) {
+            const size_t small_lds = (size_t)2 * nch * (npp + 1) * n * sizeof(u64);       // k_pp_rows_small: the chunk products of one proof in LDS
+            if (lg <= 6 && small_lds <= 48 * 1024) hipLaunchKernelGGL(k_pp_rows_small, dim3(1, 1), dim3(256), small_lds, c->stream, a);
+            else switch (nch) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<1>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<2>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
             case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<3>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
@@ -1759,7 +1761,8 @@ struct glp_session {
         a.w_n = root_of_unity(lg); a.g = GEN; a.lg = (u32)lg; a.rb = (u32)rb; a.nch = nch;
         a.pp = nullptr; a.apow_stride = a.out_stride = 0;
         for (int k = 0; k < 4; k++) a.lde_stride[k] = 0;
-        hipLaunchKernelGGL(k_final_values, dim3(nblk(n)), dim3(256), 0, c->stream, a);
+        if (lg >= 2 && lg <= 6) hipLaunchKernelGGL(k_final_values_small, dim3(1, 1), dim3(256), 0, c->stream, a);      // 4..64 points: 256 / n lanes per point
+        else hipLaunchKernelGGL(k_final_values, dim3(nblk(n)), dim3(256), 0, c->stream, a);
         GLP_HIP(hipGetLastError());
         GLP_TRY(intt_values_to_coeffs(c, fv, fcoef, 2, lg));
         hipLaunchKernelGGL(k_scale_bitrev_pow, dim3(nblk(n), 2), dim3(256), 0, c->stream, fcoef, inv(GEN), (u32)lg);

@@ -55,7 +55,7 @@ def test_poseidon_parity_edge_value_soak(ctx, oracle):
     assert bad.size == 0, "first mismatching state %d: %s" % (bad[0], [hex(int(x)) for x in st[bad[0]]])
 
 
-@pytest.mark.parametrize("lg", [0, 1, 2, 3, 4, 5, 8, 11, 12, 13, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("lg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16, 17, 18, 19, 20])
 def test_fft_ifft_parity(ctx, oracle, lg):
     rng = np.random.default_rng(100 + lg)
     ncols = 3
@@ -68,7 +68,7 @@ def test_fft_ifft_parity(ctx, oracle, lg):
     assert (ctx.ifft(f) == a).all()
 
 
-@pytest.mark.parametrize("lg,rb,shift", [(0, 3, 7), (1, 2, 7), (2, 4, 49), (3, 3, 7), (4, 1, 7 ** 4), (4, 3, 7), (6, 1, 7), (9, 3, 7 ** 16 % P), (12, 3, 7), (13, 3, 7), (14, 2, 49), (16, 3, 7),
+@pytest.mark.parametrize("lg,rb,shift", [(0, 3, 7), (1, 2, 7), (2, 4, 49), (3, 3, 7), (4, 1, 7 ** 4), (4, 3, 7), (5, 4, 7), (6, 1, 7), (7, 3, 7), (8, 4, 49), (8, 0, 7), (9, 3, 7 ** 16 % P), (12, 3, 7), (13, 3, 7), (14, 2, 49), (16, 3, 7),
                                          (17, 3, 7), (18, 1, 7), (19, 2, 49), (20, 3, 7)])
 def test_lde_parity(ctx, oracle, lg, rb, shift):
     rng = np.random.default_rng(200 + lg)
@@ -155,6 +155,16 @@ def test_leaf_hash_forms(oracle, form):
             b.free()
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("ncols,lg,rb", [(1, 5, 0), (33, 5, 0), (7, 6, 1), (5, 8, 0), (9, 7, 2)])
+def test_mid_size_transforms_ragged_column_counts(ctx, oracle, ncols, lg, rb):
+    """k_lde_mid packs several 32..256-point columns into one workgroup when a column's cosets leave room: column counts that do not fill the last one"""
+    rng = np.random.default_rng(ncols * 17 + lg)
+    co = oracle.rand_field(rng, (ncols, 1 << lg))
+    got = ctx.lde(co, rb, 7)
+    for k in range(ncols):
+        assert (got[k] == oracle.lde(co[k], rb, 7)).all()
 
 
 def test_empty_batch_is_an_error(ctx):

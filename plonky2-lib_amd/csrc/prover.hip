@@ -124,11 +124,13 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
 // The same for traces of at most 64 rows (a batch of small proofs: blockIdx.y = proof, one workgroup per proof).  k_pp_rows gives a row to a lane, and a
 // lane then walks ~1000 dependent multiplications (80 wires x two challenges, one inversion per challenge) while 56 lanes of its wave idle: 120 us per 256
 // zkdsa proofs, all of it latency.  Here a lane takes one (row, chunk, challenge): the chunk products in parallel through LDS, then one lane per
-// (row, challenge) for the prefix products, the inversion and the walk back -- ~170 dependent multiplications.  Same values in the same places.
+// (row, challenge) for the prefix products, the inversion and the walk back -- ~170 dependent multiplications -- and, since the whole trace is in this
+// workgroup, the running product over the rows as well (k_pp_block_tot / k_pp_scan_tot / k_pp_apply of the large path).  Same values in the same places.
 __global__ __launch_bounds__(256) void k_pp_rows_small(PPArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 pp_lds[];
     const u32 n = 1u << a.lg, nchunks = a.npp + 1, nch = a.nch, units = n * nchunks * nch;
     u64 *snum = pp_lds, *sden = pp_lds + units;              // [c][chunk][i]
+    u64 *rowp = pp_lds + 2 * (size_t)units, *zrow = rowp + (size_t)nch * n;      // [c][i]: row products, running products
     const size_t pk = blockIdx.y;
     if (a.chal) { a.wires += pk * a.wires_stride; a.zp += pk * a.zp_stride; }
     const u64 *ch = a.chal ? a.chal + pk * 2 * MAXCH : nullptr;
@@ -160,9 +162,25 @@ __global__ __launch_bounds__(256) void k_pp_rows_small(PPArgs a) {
         for (int chunk = (int)a.npp; chunk >= 0; chunk--) {
             const u32 col = (u32)chunk < a.npp ? nch + c * a.npp + chunk : c;
             const size_t o = (size_t)col * n + i;
-            a.zp[o] = mul(a.zp[o], ipd);
+            const u64 v = mul(a.zp[o], ipd);
+            a.zp[o] = v;
+            if ((u32)chunk == a.npp) rowp[(size_t)c * n + i] = v;          // the row's whole product
             ipd = mul(ipd, dn[(size_t)chunk * n]);
         }
+    }
+    __syncthreads();
+    // Z_i = product of the rows before i (one lane per challenge walks the <= 64 rows), then every partial product of row i times Z_i
+    if (threadIdx.x < nch) {
+        const u32 c = threadIdx.x;
+        u64 acc = 1;
+        for (u32 i = 0; i < n; i++) { const u64 r = rowp[(size_t)c * n + i]; zrow[(size_t)c * n + i] = acc; acc = mul(acc, r); }
+    }
+    __syncthreads();
+    for (u32 u = threadIdx.x; u < units; u += 256) {
+        const u32 i = u % n, k = (u / n) % nchunks, c = u / (n * nchunks);
+        const u64 z = zrow[(size_t)c * n + i];
+        if (k < a.npp) { const size_t o = (size_t)(nch + c * a.npp + k) * n + i; a.zp[o] = mul(a.zp[o], z); }
+        else a.zp[(size_t)c * n + i] = z;
     }
 }
 // K5b: product of each block of 256 row products
@@ -1554,8 +1572,9 @@ struct glp_session {
             for (u32 i = 0; i < nch; i++) { a.betas[i] = betas[i]; a.gammas[i] = gammas[i]; }
             a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
             a.chal = nullptr; a.wires_stride = 0; a.zp_stride = 0;
-            const size_t small_lds = (size_t)2 * nch * (npp + 1) * n * sizeof(u64);       // k_pp_rows_small: the chunk products of one proof in LDS
-            if (lg <= 6 && small_lds <= 48 * 1024) hipLaunchKernelGGL(k_pp_rows_small, dim3(1, 1), dim3(256), small_lds, c->stream, a);
+            const size_t small_lds = (size_t)2 * nch * (npp + 2) * n * sizeof(u64);       // k_pp_rows_small: chunk products, row products and running products of one proof in LDS
+            const bool small = lg <= 6 && small_lds <= 48 * 1024;
+            if (small) hipLaunchKernelGGL(k_pp_rows_small, dim3(1, 1), dim3(256), small_lds, c->stream, a);      // rows AND the running product over them
             else switch (nch) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<1>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
             case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<2>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
@@ -1563,10 +1582,12 @@ struct glp_session {
             default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<4>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
             }
             GLP_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_pp_block_tot, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, (size_t)0);
-            hipLaunchKernelGGL(k_pp_scan_tot, dim3(nch), dim3(256), 0, c->stream, tot, nblocks);
-            hipLaunchKernelGGL(k_pp_apply, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, nch, npp, (size_t)0);
-            GLP_HIP(hipGetLastError());
+            if (!small) {
+                hipLaunchKernelGGL(k_pp_block_tot, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, (size_t)0);
+                hipLaunchKernelGGL(k_pp_scan_tot, dim3(nch), dim3(256), 0, c->stream, tot, nblocks);
+                hipLaunchKernelGGL(k_pp_apply, dim3(nblocks, nch), dim3(256), 0, c->stream, zp, tot, (u32)lg, nblocks, nch, npp, (size_t)0);
+                GLP_HIP(hipGetLastError());
+            }
         }
         GLP_TRY(batch_build(c, zp, BATCH_VALUES, nzp, lg, rb, (int)d.cap_height, &zb.b, nullptr, 1, hasher));
         GLP_TRY(batch_cap_host(c, zb.b, cap));

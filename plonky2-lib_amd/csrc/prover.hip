@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_pp_rows(PPArgs a) {
     }
 }
 
-// The same for traces of at most 64 rows (a batch of small proofs: blockIdx.y = proof, one workgroup per proof).  k_pp_rows gives a row to a lane, and a
+// The same for traces of at most 128 rows (a batch of small proofs: blockIdx.y = proof, one workgroup per proof).  k_pp_rows gives a row to a lane, and a
 // lane then walks ~1000 dependent multiplications (80 wires x two challenges, one inversion per challenge) while 56 lanes of its wave idle: 120 us per 256
 // zkdsa proofs, all of it latency.  Here a lane takes one (row, chunk, challenge): the chunk products in parallel through LDS, then one lane per
 // (row, challenge) for the prefix products, the inversion and the walk back -- ~170 dependent multiplications -- and, since the whole trace is in this
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_pp_rows_small(PPArgs a) {
         }
     }
     __syncthreads();
-    // Z_i = product of the rows before i (one lane per challenge walks the <= 64 rows), then every partial product of row i times Z_i
+    // Z_i = product of the rows before i (one lane per challenge walks the <= 128 rows), then every partial product of row i times Z_i
     if (threadIdx.x < nch) {
         const u32 c = threadIdx.x;
         u64 acc = 1;
@@ -1095,11 +1095,11 @@ __global__ __launch_bounds__(256) void k_final_values(FVArgs a) {
     a.out[q] = f.a; a.out[n + q] = f.b;
 }
 
-// The same for at most 64 points per proof (a batch of small proofs: blockIdx.y = proof, one workgroup per proof): 256 / n lanes share a point, each
+// The same for at most 128 points per proof (a batch of small proofs: blockIdx.y = proof, one workgroup per proof): 256 / n lanes share a point, each
 // takes every (256 / n)-th column of the four oracles, an xor-butterfly adds the partial sums up, and lanes 0 and 1 of the group invert the two
 // denominators side by side.  k_final_values walks ~250 columns and two extension inversions per lane with 8 lanes live: 105 us per 256 zkdsa proofs.
 __global__ __launch_bounds__(256) void k_final_values_small(FVArgs a) {
-    const u32 n = 1u << a.lg, lpp = 256u >> a.lg;            // lanes per point: 4 .. 256
+    const u32 n = 1u << a.lg, lpp = 256u >> a.lg;            // lanes per point: 2 .. 64
     const size_t N = (size_t)n << a.rb;
     const u32 q = threadIdx.x / lpp, t = threadIdx.x % lpp;
     if (a.pp) {
@@ -1573,7 +1573,7 @@ struct glp_session {
             a.w_n = root_of_unity(lg); a.lg = (u32)lg; a.nr = nr; a.nch = nch; a.npp = npp; a.qdf = qdf;
             a.chal = nullptr; a.wires_stride = 0; a.zp_stride = 0;
             const size_t small_lds = (size_t)2 * nch * (npp + 2) * n * sizeof(u64);       // k_pp_rows_small: chunk products, row products and running products of one proof in LDS
-            const bool small = lg <= 6 && small_lds <= 48 * 1024;
+            const bool small = lg <= 7 && small_lds <= 64 * 1024;
             if (small) hipLaunchKernelGGL(k_pp_rows_small, dim3(1, 1), dim3(256), small_lds, c->stream, a);      // rows AND the running product over them
             else switch (nch) {
             case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pp_rows<1>), dim3(nblocks), dim3(256), 0, c->stream, a); break;
@@ -1782,7 +1782,7 @@ struct glp_session {
         a.w_n = root_of_unity(lg); a.g = GEN; a.lg = (u32)lg; a.rb = (u32)rb; a.nch = nch;
         a.pp = nullptr; a.apow_stride = a.out_stride = 0;
         for (int k = 0; k < 4; k++) a.lde_stride[k] = 0;
-        if (lg >= 2 && lg <= 6) hipLaunchKernelGGL(k_final_values_small, dim3(1, 1), dim3(256), 0, c->stream, a);      // 4..64 points: 256 / n lanes per point
+        if (lg >= 2 && lg <= 7) hipLaunchKernelGGL(k_final_values_small, dim3(1, 1), dim3(256), 0, c->stream, a);      // 4..128 points: 256 / n lanes per point
         else hipLaunchKernelGGL(k_final_values, dim3(nblk(n)), dim3(256), 0, c->stream, a);
         GLP_HIP(hipGetLastError());
         GLP_TRY(intt_values_to_coeffs(c, fv, fcoef, 2, lg));
